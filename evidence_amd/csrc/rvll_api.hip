@@ -1,0 +1,713 @@
+// rvll_api.hip — host side of the C-ABI declared in include/rvll.h.
+//
+// One handle = one device + two HIP streams (compute, comm) + resident epoch
+// table, layout and batch buffers.  No PyTorch, no other runtime: plain HIP, and
+// RCCL (loaded lazily with dlopen) for the multi-GPU all-gather.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+// the C-ABI entry points are the only exported symbols (built with -fvisibility=hidden)
+#pragma GCC visibility push(default)
+#include "rvll.h"
+#pragma GCC visibility pop
+#include "rvll_kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                               \
+    do {                                                                            \
+        hipError_t e_ = (expr);                                                     \
+        if (e_ != hipSuccess)                                                       \
+            return fail(e_ == hipErrorOutOfMemory ? RVLL_E_NOMEM : RVLL_E_HIP,      \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),      \
+                        __FILE__, __LINE__);                                        \
+    } while (0)
+
+// ---- RCCL, resolved at run time so the library loads on boxes without it ----
+struct Id128 { char bytes[RVLL_COMM_ID_BYTES]; };   // ncclUniqueId, passed by value
+static_assert(sizeof(Id128) == 128, "ncclUniqueId is 128 bytes");
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, Id128, int) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+constexpr int kNcclFloat64 = 8;   // ncclDouble / ncclFloat64 in rccl.h
+
+Rccl g_rccl;
+
+int rccl_load()
+{
+    if (g_rccl.lib) return RVLL_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* lib = nullptr;
+    for (const char* n : names) { lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
+    if (!lib) return fail(RVLL_E_RCCL, "cannot dlopen librccl: %s", dlerror());
+    Rccl r;
+    r.lib = lib;
+    r.GetUniqueId    = (int (*)(void*))dlsym(lib, "ncclGetUniqueId");
+    r.CommInitRank   = (int (*)(void**, int, Id128, int))dlsym(lib, "ncclCommInitRank");
+    r.AllGather      = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(lib, "ncclAllGather");
+    r.CommDestroy    = (int (*)(void*))dlsym(lib, "ncclCommDestroy");
+    r.GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy || !r.GetErrorString) {
+        dlclose(lib);
+        return fail(RVLL_E_RCCL, "librccl lacks an expected nccl* symbol");
+    }
+    g_rccl = r;
+    return RVLL_OK;
+}
+
+#define RCCL_TRY(expr)                                                              \
+    do {                                                                            \
+        int r_ = (expr);                                                            \
+        if (r_ != 0)                                                                \
+            return fail(RVLL_E_RCCL, "%s failed: %s", #expr, g_rccl.GetErrorString(r_)); \
+    } while (0)
+
+template <typename T>
+void dev_free(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
+
+}  // namespace
+
+struct rvll_handle {
+    int device = 0;
+    hipStream_t compute = nullptr;
+    hipStream_t comm = nullptr;
+    hipEvent_t  ev_compute_done = nullptr;
+
+    // layout (host mirror, then device copies)
+    rvll_layout L{};
+    std::vector<rvll_planet> planets;
+    std::vector<rvll_inst>   insts;
+    std::vector<rvll_slot>   linslots;
+    rvll_planet* d_planets = nullptr;
+    rvll_inst*   d_insts = nullptr;
+    rvll_slot*   d_linslots = nullptr;
+
+    // resident epoch table
+    int Ne = 0;
+    double*  d_t = nullptr;
+    double*  d_y = nullptr;
+    double*  d_s2 = nullptr;
+    int32_t* d_inst = nullptr;
+    double*  d_linpar = nullptr;
+    double   cte = 0.;
+
+    // priors
+    bool have_priors = false;
+    rvll_prior* d_priors = nullptr;
+    std::vector<double*> d_tables;
+
+    // batch buffers
+    long long cap = 0;
+    double*  d_theta = nullptr;
+    double*  d_cube = nullptr;
+    double*  d_logL = nullptr;
+    int32_t* d_flags = nullptr;
+
+    // geometry
+    int pb_override = 0;
+    int chunk_items = 4096;
+    int n_cu = 256;
+
+    // multi-GPU
+    void* nccl_comm = nullptr;
+    int nranks = 1, rank = 0;
+    long long gather_cap = 0;
+    double* d_gather = nullptr;
+};
+
+namespace {
+
+int use_device(rvll_handle* h)
+{
+    if (!h) return fail(RVLL_E_INVALID, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    return RVLL_OK;
+}
+
+bool slot_ok(const rvll_slot& s, int D) { return s.idx < D; }
+
+int validate_layout(const rvll_layout* L)
+{
+    if (!L) return fail(RVLL_E_INVALID, "layout is null");
+    if (L->struct_size != (int32_t)sizeof(rvll_layout))
+        return fail(RVLL_E_INVALID, "rvll_layout.struct_size %d != %zu (ABI mismatch)",
+                    L->struct_size, sizeof(rvll_layout));
+    if (L->ndim < 0 || L->nplanets < 0 || L->ninst < 1 || L->nlinpar < 0)
+        return fail(RVLL_E_INVALID, "layout counts out of range (ndim %d, nplanets %d, ninst %d, nlinpar %d)",
+                    L->ndim, L->nplanets, L->ninst, L->nlinpar);
+    if (L->nplanets > 0 && !L->planets) return fail(RVLL_E_INVALID, "planets pointer is null");
+    if (!L->insts) return fail(RVLL_E_INVALID, "insts pointer is null");
+    if (L->nlinpar > 0 && !L->linpar) return fail(RVLL_E_INVALID, "linpar pointer is null");
+    if (L->precision != RVLL_PREC_FP64) return fail(RVLL_E_UNSUPPORTED, "only fp64 is built");
+    if (!(L->tol > 0.) || L->itmax < 1) return fail(RVLL_E_INVALID, "tol/itmax out of range");
+    const int D = L->ndim;
+    for (int i = 0; i < L->nplanets; ++i) {
+        const rvll_planet& p = L->planets[i];
+        if (!slot_ok(p.k, D) || !slot_ok(p.p, D) || !slot_ok(p.e1, D) || !slot_ok(p.e2, D) ||
+            !slot_ok(p.anom, D) || !slot_ok(p.epoch, D))
+            return fail(RVLL_E_INVALID, "planet %d: slot index >= ndim", i + 1);
+        if (p.k_kind < 0 || p.k_kind > 1 || p.p_kind < 0 || p.p_kind > 1 || p.ecc_kind < 0 ||
+            p.ecc_kind > 2 || p.anom_kind < 0 || p.anom_kind > 1)
+            return fail(RVLL_E_INVALID, "planet %d: bad parametrisation enum", i + 1);
+    }
+    for (int i = 0; i < L->ninst; ++i)
+        if (!slot_ok(L->insts[i].offset, D) || (L->has_jitter && !slot_ok(L->insts[i].jitter, D)))
+            return fail(RVLL_E_INVALID, "instrument %d: slot index >= ndim", i);
+    for (int i = 0; i < 4; ++i)
+        if (!slot_ok(L->drift[i], D)) return fail(RVLL_E_INVALID, "drift slot index >= ndim");
+    if (!slot_ok(L->tref, D)) return fail(RVLL_E_INVALID, "tref slot index >= ndim");
+    for (int i = 0; i < L->nlinpar; ++i)
+        if (!slot_ok(L->linpar[i], D)) return fail(RVLL_E_INVALID, "linpar slot index >= ndim");
+    return RVLL_OK;
+}
+
+// Launch geometry: how many live points one 256-thread workgroup takes.  Lane
+// efficiency (flattened items per 256-wide round) x how evenly the grid fills the
+// CUs at the occupancy the kernel reaches.
+int choose_points_per_block(const rvll_handle* h, long long B)
+{
+    if (h->pb_override > 0) return std::min(h->pb_override, rvll::kMaxPointsPerBlock);
+    const int Ne = h->Ne;
+    const int T = rvll::kThreads;
+    const int blocks_per_cu = 4;
+    const double slots = (double)h->n_cu * blocks_per_cu;
+    int best = 1;
+    double best_score = -1.;
+    for (int pb = 1; pb <= rvll::kMaxPointsPerBlock; ++pb) {
+        if ((long long)pb > std::max(1LL, B)) break;
+        const long long items = (long long)pb * Ne;
+        if (pb > 1 && items > h->chunk_items) break;
+        const long long rounds = (items + T - 1) / T;
+        const double lane_eff = (double)items / (double)(rounds * T);
+        const double blocks = std::ceil((double)B / pb);
+        const double waves_of_blocks = std::ceil(blocks / slots);
+        const double fill = blocks / (waves_of_blocks * slots);
+        // many small grids only half-fill the chip; weigh that softly (occupancy still hides latency)
+        const double score = lane_eff * (0.5 + 0.5 * fill);
+        if (score > best_score + 1e-9) { best_score = score; best = pb; }
+    }
+    return best;
+}
+
+int build_args(rvll_handle* h, const double* d_theta, double* d_logL, int32_t* d_flags,
+               long long B, rvll::LoglikeArgs* out)
+{
+    rvll::LoglikeArgs a{};
+    a.theta = d_theta; a.logL = d_logL; a.flags = d_flags; a.B = B;
+    a.t = h->d_t; a.y = h->d_y; a.s2 = h->d_s2; a.inst = h->d_inst; a.linpar = h->d_linpar;
+    a.Ne = h->Ne;
+    a.planets = h->d_planets; a.insts = h->d_insts; a.linslots = h->d_linslots;
+    a.D = h->L.ndim; a.Np = h->L.nplanets; a.Ni = h->L.ninst; a.nlin = h->L.nlinpar;
+    a.has_jitter = h->L.has_jitter; a.has_drift = h->L.has_drift;
+    a.tref_from_data = h->L.tref_from_data;
+    for (int i = 0; i < 4; ++i) a.drift[i] = h->L.drift[i];
+    a.tref = h->L.tref;
+    a.tol = h->L.tol; a.itmax = h->L.itmax;
+    a.PB = choose_points_per_block(h, B);
+    a.CH = std::min(h->chunk_items, std::max(rvll::kThreads, a.PB * h->Ne));
+    a.CH = (a.CH + 1) & ~1;
+    a.cte = h->cte;
+    // shrink PB until the LDS carve fits the 64 KiB default dynamic limit
+    while (a.PB > 1 && rvll::loglike_lds_bytes(a) > 60 * 1024) {
+        a.PB -= 1;
+        a.CH = std::min(h->chunk_items, std::max(rvll::kThreads, a.PB * h->Ne));
+        a.CH = (a.CH + 1) & ~1;
+    }
+    if (rvll::loglike_lds_bytes(a) > 64 * 1024)
+        return fail(RVLL_E_UNSUPPORTED, "per-point state (%d parameters, %d planets) exceeds the LDS budget",
+                    a.D, a.Np);
+    *out = a;
+    return RVLL_OK;
+}
+
+int ensure_capacity(rvll_handle* h, long long B)
+{
+    if (B <= h->cap) return RVLL_OK;
+    long long cap = std::max<long long>(B, 1024);
+    dev_free(h->d_theta); dev_free(h->d_cube); dev_free(h->d_logL); dev_free(h->d_flags);
+    h->cap = 0;
+    const size_t D = (size_t)std::max(1, h->L.ndim);
+    HIP_TRY(hipMalloc(&h->d_theta, sizeof(double) * D * (size_t)cap));
+    HIP_TRY(hipMalloc(&h->d_cube,  sizeof(double) * D * (size_t)cap));
+    HIP_TRY(hipMalloc(&h->d_logL,  sizeof(double) * (size_t)cap));
+    HIP_TRY(hipMalloc(&h->d_flags, sizeof(int32_t) * (size_t)cap));
+    h->cap = cap;
+    return RVLL_OK;
+}
+
+void free_priors(rvll_handle* h)
+{
+    for (double*& p : h->d_tables) dev_free(p);
+    h->d_tables.clear();
+    dev_free(h->d_priors);
+    h->have_priors = false;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rvll_last_error(void) { return g_last_error.c_str(); }
+
+int rvll_version(int32_t* major, int32_t* minor)
+{
+    if (major) *major = RVLL_VERSION_MAJOR;
+    if (minor) *minor = RVLL_VERSION_MINOR;
+    return RVLL_OK;
+}
+
+int rvll_device_count(int32_t* count)
+{
+    if (!count) return fail(RVLL_E_INVALID, "count is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(RVLL_E_NODEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = n;
+    return RVLL_OK;
+}
+
+int rvll_device_name(int32_t device, char* buf, int32_t buflen)
+{
+    if (!buf || buflen < 1) return fail(RVLL_E_INVALID, "bad buffer");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    snprintf(buf, (size_t)buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return RVLL_OK;
+}
+
+int rvll_create(const rvll_layout* layout, const double* time, const double* vrad,
+                const double* svrad, const int32_t* inst, int32_t n_epochs,
+                const double* linpar_series, int32_t device, rvll_handle** out)
+{
+    if (!out) return fail(RVLL_E_INVALID, "out is null");
+    *out = nullptr;
+    int rc = validate_layout(layout);
+    if (rc) return rc;
+    if (!time || !vrad || !svrad || !inst || n_epochs < 1)
+        return fail(RVLL_E_INVALID, "epoch table is empty or null");
+    if (layout->nlinpar > 0 && !linpar_series)
+        return fail(RVLL_E_INVALID, "nlinpar > 0 but linpar_series is null");
+    for (int j = 0; j < n_epochs; ++j)
+        if (inst[j] < 0 || inst[j] >= layout->ninst)
+            return fail(RVLL_E_INVALID, "inst[%d] = %d outside [0, %d)", j, inst[j], layout->ninst);
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1)
+        return fail(RVLL_E_NODEVICE, "no HIP device available (%s); rvll has no CPU path",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device < 0) HIP_TRY(hipGetDevice(&device));
+    if (device >= ndev) return fail(RVLL_E_NODEVICE, "device %d >= device count %d", device, ndev);
+
+    rvll_handle* h = new (std::nothrow) rvll_handle;
+    if (!h) return fail(RVLL_E_NOMEM, "out of host memory");
+    h->device = device;
+    h->L = *layout;
+    h->planets.assign(layout->planets, layout->planets + layout->nplanets);
+    h->insts.assign(layout->insts, layout->insts + layout->ninst);
+    if (layout->nlinpar) h->linslots.assign(layout->linpar, layout->linpar + layout->nlinpar);
+    h->L.planets = h->planets.data();
+    h->L.insts = h->insts.data();
+    h->L.linpar = h->linslots.data();
+    h->Ne = n_epochs;
+    h->cte = -0.5 * (double)n_epochs * std::log(2 * M_PI);          // rvmodel:77-78
+
+#define CREATE_TRY(expr)                                                             \
+    do {                                                                             \
+        hipError_t e2_ = (expr);                                                     \
+        if (e2_ != hipSuccess) {                                                     \
+            int c_ = fail(e2_ == hipErrorOutOfMemory ? RVLL_E_NOMEM : RVLL_E_HIP,    \
+                          "%s failed: %s", #expr, hipGetErrorString(e2_));           \
+            rvll_destroy(h);                                                         \
+            return c_;                                                               \
+        }                                                                            \
+    } while (0)
+
+    CREATE_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    CREATE_TRY(hipGetDeviceProperties(&prop, device));
+    h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    CREATE_TRY(hipStreamCreateWithFlags(&h->compute, hipStreamNonBlocking));
+    CREATE_TRY(hipStreamCreateWithFlags(&h->comm, hipStreamNonBlocking));
+    CREATE_TRY(hipEventCreateWithFlags(&h->ev_compute_done, hipEventDisableTiming));
+
+    const size_t nb = sizeof(double) * (size_t)n_epochs;
+    std::vector<double> s2((size_t)n_epochs);
+    for (int j = 0; j < n_epochs; ++j) s2[j] = svrad[j] * svrad[j];  // rvmodel:190,192
+    CREATE_TRY(hipMalloc(&h->d_t, nb));
+    CREATE_TRY(hipMalloc(&h->d_y, nb));
+    CREATE_TRY(hipMalloc(&h->d_s2, nb));
+    CREATE_TRY(hipMalloc(&h->d_inst, sizeof(int32_t) * (size_t)n_epochs));
+    CREATE_TRY(hipMemcpy(h->d_t, time, nb, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(h->d_y, vrad, nb, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(h->d_s2, s2.data(), nb, hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(h->d_inst, inst, sizeof(int32_t) * (size_t)n_epochs, hipMemcpyHostToDevice));
+    if (layout->nlinpar) {
+        CREATE_TRY(hipMalloc(&h->d_linpar, nb * (size_t)layout->nlinpar));
+        CREATE_TRY(hipMemcpy(h->d_linpar, linpar_series, nb * (size_t)layout->nlinpar, hipMemcpyHostToDevice));
+        CREATE_TRY(hipMalloc(&h->d_linslots, sizeof(rvll_slot) * (size_t)layout->nlinpar));
+        CREATE_TRY(hipMemcpy(h->d_linslots, h->linslots.data(), sizeof(rvll_slot) * (size_t)layout->nlinpar, hipMemcpyHostToDevice));
+    }
+    if (layout->nplanets) {
+        CREATE_TRY(hipMalloc(&h->d_planets, sizeof(rvll_planet) * (size_t)layout->nplanets));
+        CREATE_TRY(hipMemcpy(h->d_planets, h->planets.data(), sizeof(rvll_planet) * (size_t)layout->nplanets, hipMemcpyHostToDevice));
+    }
+    CREATE_TRY(hipMalloc(&h->d_insts, sizeof(rvll_inst) * (size_t)layout->ninst));
+    CREATE_TRY(hipMemcpy(h->d_insts, h->insts.data(), sizeof(rvll_inst) * (size_t)layout->ninst, hipMemcpyHostToDevice));
+#undef CREATE_TRY
+    *out = h;
+    return RVLL_OK;
+}
+
+int rvll_destroy(rvll_handle* h)
+{
+    if (!h) return RVLL_OK;
+    (void)hipSetDevice(h->device);
+    if (h->nccl_comm && g_rccl.lib) { (void)g_rccl.CommDestroy(h->nccl_comm); h->nccl_comm = nullptr; }
+    if (h->compute) (void)hipStreamSynchronize(h->compute);
+    if (h->comm) (void)hipStreamSynchronize(h->comm);
+    free_priors(h);
+    dev_free(h->d_theta); dev_free(h->d_cube); dev_free(h->d_logL); dev_free(h->d_flags);
+    dev_free(h->d_gather);
+    dev_free(h->d_t); dev_free(h->d_y); dev_free(h->d_s2); dev_free(h->d_inst); dev_free(h->d_linpar);
+    dev_free(h->d_planets); dev_free(h->d_insts); dev_free(h->d_linslots);
+    if (h->ev_compute_done) (void)hipEventDestroy(h->ev_compute_done);
+    if (h->compute) (void)hipStreamDestroy(h->compute);
+    if (h->comm) (void)hipStreamDestroy(h->comm);
+    delete h;
+    return RVLL_OK;
+}
+
+int rvll_set_points_per_block(rvll_handle* h, int32_t points_per_block)
+{
+    if (!h) return fail(RVLL_E_INVALID, "null handle");
+    if (points_per_block > rvll::kMaxPointsPerBlock)
+        return fail(RVLL_E_INVALID, "points_per_block > %d", rvll::kMaxPointsPerBlock);
+    h->pb_override = points_per_block > 0 ? points_per_block : 0;
+    return RVLL_OK;
+}
+
+// ---- priors -------------------------------------------------------------------
+int rvll_set_priors(rvll_handle* h, const rvll_prior* priors, int32_t ndim)
+{
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!priors || ndim != h->L.ndim)
+        return fail(RVLL_E_INVALID, "set_priors: ndim %d != layout ndim %d (or priors null)", ndim, h->L.ndim);
+    for (int d = 0; d < ndim; ++d) {
+        const rvll_prior& p = priors[d];
+        switch (p.kind) {
+        case RVLL_PRIOR_UNIFORM: case RVLL_PRIOR_JEFFREYS: case RVLL_PRIOR_MODJEFFREYS:
+        case RVLL_PRIOR_UNIFORMFREQUENCY: case RVLL_PRIOR_NORMAL: case RVLL_PRIOR_LOGNORMAL:
+        case RVLL_PRIOR_TRUNCRAYLEIGH:
+            break;
+        case RVLL_PRIOR_TABLE:
+            if (p.table_n < 2 || !p.table_cdf || !p.table_x)
+                return fail(RVLL_E_INVALID, "prior %d: table needs >= 2 knots", d);
+            for (int i = 1; i < p.table_n; ++i)
+                if (!(p.table_cdf[i] >= p.table_cdf[i - 1]))
+                    return fail(RVLL_E_INVALID, "prior %d: table knots not sorted at %d", d, i);
+            break;
+        default:
+            return fail(RVLL_E_UNSUPPORTED, "prior %d: kind %d has no device implementation in this build", d, p.kind);
+        }
+    }
+    free_priors(h);
+    std::vector<rvll_prior> dev(priors, priors + ndim);
+    for (int d = 0; d < ndim; ++d) {
+        if (dev[d].kind != RVLL_PRIOR_TABLE) { dev[d].table_cdf = dev[d].table_x = nullptr; continue; }
+        const size_t nb = sizeof(double) * (size_t)dev[d].table_n;
+        double *dc = nullptr, *dx = nullptr;
+        HIP_TRY(hipMalloc(&dc, nb)); h->d_tables.push_back(dc);
+        HIP_TRY(hipMalloc(&dx, nb)); h->d_tables.push_back(dx);
+        HIP_TRY(hipMemcpy(dc, priors[d].table_cdf, nb, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(dx, priors[d].table_x, nb, hipMemcpyHostToDevice));
+        dev[d].table_cdf = dc;
+        dev[d].table_x = dx;
+    }
+    HIP_TRY(hipMalloc(&h->d_priors, sizeof(rvll_prior) * (size_t)std::max(1, ndim)));
+    if (ndim) HIP_TRY(hipMemcpy(h->d_priors, dev.data(), sizeof(rvll_prior) * (size_t)ndim, hipMemcpyHostToDevice));
+    h->have_priors = true;
+    return RVLL_OK;
+}
+
+// ---- device-resident forms ----------------------------------------------------
+int rvll_dev_reserve(rvll_handle* h, int64_t B)
+{
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (B < 0) return fail(RVLL_E_INVALID, "B < 0");
+    return ensure_capacity(h, B);
+}
+
+int rvll_dev_upload_theta(rvll_handle* h, const double* theta, int64_t B)
+{
+    int rc = rvll_dev_reserve(h, B);
+    if (rc) return rc;
+    if (B == 0) return RVLL_OK;
+    if (!theta) return fail(RVLL_E_INVALID, "theta is null");
+    HIP_TRY(hipMemcpyAsync(h->d_theta, theta, sizeof(double) * (size_t)B * (size_t)h->L.ndim,
+                           hipMemcpyHostToDevice, h->compute));
+    HIP_TRY(hipStreamSynchronize(h->compute));
+    return RVLL_OK;
+}
+
+int rvll_dev_upload_cube(rvll_handle* h, const double* cube, int64_t B)
+{
+    int rc = rvll_dev_reserve(h, B);
+    if (rc) return rc;
+    if (B == 0) return RVLL_OK;
+    if (!cube) return fail(RVLL_E_INVALID, "cube is null");
+    HIP_TRY(hipMemcpyAsync(h->d_cube, cube, sizeof(double) * (size_t)B * (size_t)h->L.ndim,
+                           hipMemcpyHostToDevice, h->compute));
+    HIP_TRY(hipStreamSynchronize(h->compute));
+    return RVLL_OK;
+}
+
+int rvll_dev_fill_cube(rvll_handle* h, int64_t B, uint64_t seed)
+{
+    int rc = rvll_dev_reserve(h, B);
+    if (rc) return rc;
+    HIP_TRY(rvll::launch_fill_cube(h->d_cube, (long long)B * h->L.ndim, seed, h->compute));
+    return RVLL_OK;
+}
+
+int rvll_dev_prior(rvll_handle* h, int64_t B)
+{
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!h->have_priors) return fail(RVLL_E_NOPRIORS, "rvll_set_priors has not been called");
+    if (B < 0 || B > h->cap) return fail(RVLL_E_INVALID, "B %lld outside reserved capacity %lld", (long long)B, h->cap);
+    rvll::PriorArgs a{h->d_cube, h->d_theta, (long long)B, h->L.ndim, h->d_priors};
+    HIP_TRY(rvll::launch_prior(a, h->compute));
+    return RVLL_OK;
+}
+
+int rvll_dev_loglike(rvll_handle* h, int64_t B)
+{
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (B < 0 || B > h->cap) return fail(RVLL_E_INVALID, "B %lld outside reserved capacity %lld", (long long)B, h->cap);
+    if (B == 0) return RVLL_OK;
+    rvll::LoglikeArgs a;
+    rc = build_args(h, h->d_theta, h->d_logL, h->d_flags, B, &a);
+    if (rc) return rc;
+    HIP_TRY(rvll::launch_loglike(a, h->compute));
+    return RVLL_OK;
+}
+
+int rvll_dev_download(rvll_handle* h, int64_t B, double* theta, double* logL, int32_t* flags)
+{
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (B < 0 || B > h->cap) return fail(RVLL_E_INVALID, "B %lld outside reserved capacity %lld", (long long)B, h->cap);
+    if (B > 0) {
+        if (theta) HIP_TRY(hipMemcpyAsync(theta, h->d_theta, sizeof(double) * (size_t)B * (size_t)h->L.ndim, hipMemcpyDeviceToHost, h->compute));
+        if (logL)  HIP_TRY(hipMemcpyAsync(logL, h->d_logL, sizeof(double) * (size_t)B, hipMemcpyDeviceToHost, h->compute));
+        if (flags) HIP_TRY(hipMemcpyAsync(flags, h->d_flags, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, h->compute));
+    }
+    HIP_TRY(hipStreamSynchronize(h->compute));
+    return RVLL_OK;
+}
+
+int rvll_dev_sync(rvll_handle* h)
+{
+    int rc = use_device(h);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->compute));
+    HIP_TRY(hipStreamSynchronize(h->comm));
+    return RVLL_OK;
+}
+
+int rvll_dev_time_loglike(rvll_handle* h, int64_t B, int32_t warmup, int32_t iters, rvll_timing* out)
+{
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!out || iters < 1 || warmup < 0) return fail(RVLL_E_INVALID, "bad timing arguments");
+    if (B < 1 || B > h->cap) return fail(RVLL_E_INVALID, "B %lld outside reserved capacity %lld", (long long)B, h->cap);
+    rvll::LoglikeArgs a;
+    rc = build_args(h, h->d_theta, h->d_logL, h->d_flags, B, &a);
+    if (rc) return rc;
+    for (int i = 0; i < warmup; ++i) HIP_TRY(rvll::launch_loglike(a, h->compute));
+    std::vector<hipEvent_t> ev((size_t)iters + 1, nullptr);
+    int status = RVLL_OK;
+    for (auto& e : ev)
+        if (hipEventCreate(&e) != hipSuccess) { status = fail(RVLL_E_HIP, "hipEventCreate failed"); break; }
+    if (status == RVLL_OK) {
+        hipError_t e = hipEventRecord(ev[0], h->compute);
+        for (int i = 0; i < iters && e == hipSuccess; ++i) {
+            e = rvll::launch_loglike(a, h->compute);
+            if (e == hipSuccess) e = hipEventRecord(ev[(size_t)i + 1], h->compute);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(h->compute);
+        if (e != hipSuccess) status = fail(RVLL_E_HIP, "timed launches failed: %s", hipGetErrorString(e));
+    }
+    if (status == RVLL_OK) {
+        std::vector<double> ms((size_t)iters);
+        double sum = 0.;
+        for (int i = 0; i < iters; ++i) {
+            float f = 0.f;
+            (void)hipEventElapsedTime(&f, ev[(size_t)i], ev[(size_t)i + 1]);
+            ms[(size_t)i] = f;
+            sum += f;
+        }
+        float total = 0.f;
+        (void)hipEventElapsedTime(&total, ev.front(), ev.back());
+        std::sort(ms.begin(), ms.end());
+        out->kernel_ms_mean = sum / iters;
+        out->kernel_ms_min = ms.front();
+        out->kernel_ms_median = ms[(size_t)iters / 2];
+        out->total_ms = total;
+        out->evals = (int64_t)B * iters;
+        out->launches = iters;
+        out->points_per_block = a.PB;
+        out->blocks = (int32_t)((B + a.PB - 1) / a.PB);
+        out->threads = rvll::kThreads;
+    }
+    for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    return status;
+}
+
+// ---- host-buffer hot calls -------------------------------------------------------
+int rvll_loglike_batch(rvll_handle* h, const double* theta, int64_t B, double* logL, int32_t* flags)
+{
+    if (B < 0) return fail(RVLL_E_INVALID, "B < 0");
+    if (B == 0) return use_device(h);
+    if (!theta || !logL) return fail(RVLL_E_INVALID, "theta/logL is null");
+    int rc = rvll_dev_upload_theta(h, theta, B);
+    if (rc) return rc;
+    rc = rvll_dev_loglike(h, B);
+    if (rc) return rc;
+    return rvll_dev_download(h, B, nullptr, logL, flags);
+}
+
+int rvll_prior_batch(rvll_handle* h, const double* cube, int64_t B, double* theta)
+{
+    if (B < 0) return fail(RVLL_E_INVALID, "B < 0");
+    if (h && !h->have_priors) return fail(RVLL_E_NOPRIORS, "rvll_set_priors has not been called");
+    if (B == 0) return use_device(h);
+    if (!cube || !theta) return fail(RVLL_E_INVALID, "cube/theta is null");
+    int rc = rvll_dev_upload_cube(h, cube, B);
+    if (rc) return rc;
+    rc = rvll_dev_prior(h, B);
+    if (rc) return rc;
+    return rvll_dev_download(h, B, theta, nullptr, nullptr);
+}
+
+int rvll_prior_loglike_batch(rvll_handle* h, const double* cube, int64_t B,
+                             double* theta_out, double* logL, int32_t* flags)
+{
+    if (B < 0) return fail(RVLL_E_INVALID, "B < 0");
+    if (h && !h->have_priors) return fail(RVLL_E_NOPRIORS, "rvll_set_priors has not been called");
+    if (B == 0) return use_device(h);
+    if (!cube || !logL) return fail(RVLL_E_INVALID, "cube/logL is null");
+    int rc = rvll_dev_upload_cube(h, cube, B);
+    if (rc) return rc;
+    rc = rvll_dev_prior(h, B);
+    if (rc) return rc;
+    rc = rvll_dev_loglike(h, B);
+    if (rc) return rc;
+    return rvll_dev_download(h, B, theta_out, logL, flags);
+}
+
+// ---- multi-GPU ---------------------------------------------------------------------
+int rvll_comm_unique_id(unsigned char id[RVLL_COMM_ID_BYTES])
+{
+    if (!id) return fail(RVLL_E_INVALID, "id is null");
+    int rc = rccl_load();
+    if (rc) return rc;
+    Id128 u;
+    memset(&u, 0, sizeof u);
+    RCCL_TRY(g_rccl.GetUniqueId(&u));
+    memcpy(id, u.bytes, RVLL_COMM_ID_BYTES);
+    return RVLL_OK;
+}
+
+int rvll_comm_init(rvll_handle* h, const unsigned char id[RVLL_COMM_ID_BYTES], int32_t nranks, int32_t rank)
+{
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!id || nranks < 1 || rank < 0 || rank >= nranks) return fail(RVLL_E_INVALID, "bad comm arguments");
+    rc = rccl_load();
+    if (rc) return rc;
+    if (h->nccl_comm) { (void)g_rccl.CommDestroy(h->nccl_comm); h->nccl_comm = nullptr; }
+    Id128 u;
+    memcpy(u.bytes, id, RVLL_COMM_ID_BYTES);
+    RCCL_TRY(g_rccl.CommInitRank(&h->nccl_comm, nranks, u, rank));
+    h->nranks = nranks;
+    h->rank = rank;
+    return RVLL_OK;
+}
+
+int rvll_allgather_logl(rvll_handle* h, int64_t B_local)
+{
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!h->nccl_comm) return fail(RVLL_E_RCCL, "rvll_comm_init has not been called");
+    if (B_local < 1 || B_local > h->cap) return fail(RVLL_E_INVALID, "B_local %lld outside reserved capacity %lld", (long long)B_local, h->cap);
+    const long long total = (long long)B_local * h->nranks;
+    if (total > h->gather_cap) {
+        HIP_TRY(hipStreamSynchronize(h->comm));
+        dev_free(h->d_gather);
+        h->gather_cap = 0;
+        HIP_TRY(hipMalloc(&h->d_gather, sizeof(double) * (size_t)total));
+        h->gather_cap = total;
+    }
+    // comm stream waits for the log-L kernel; the next batch's kernel may start meanwhile
+    HIP_TRY(hipEventRecord(h->ev_compute_done, h->compute));
+    HIP_TRY(hipStreamWaitEvent(h->comm, h->ev_compute_done, 0));
+    RCCL_TRY(g_rccl.AllGather(h->d_logL, h->d_gather, (size_t)B_local, kNcclFloat64, h->nccl_comm, h->comm));
+    return RVLL_OK;
+}
+
+int rvll_download_gathered(rvll_handle* h, int64_t B_total, double* logL_all)
+{
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!logL_all || B_total < 1 || B_total > h->gather_cap) return fail(RVLL_E_INVALID, "bad gathered download");
+    HIP_TRY(hipMemcpyAsync(logL_all, h->d_gather, sizeof(double) * (size_t)B_total, hipMemcpyDeviceToHost, h->comm));
+    HIP_TRY(hipStreamSynchronize(h->comm));
+    return RVLL_OK;
+}
+
+int rvll_comm_destroy(rvll_handle* h)
+{
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (h->nccl_comm && g_rccl.lib) {
+        HIP_TRY(hipStreamSynchronize(h->comm));
+        RCCL_TRY(g_rccl.CommDestroy(h->nccl_comm));
+    }
+    h->nccl_comm = nullptr;
+    h->nranks = 1;
+    h->rank = 0;
+    return RVLL_OK;
+}
+
+}  // extern "C"

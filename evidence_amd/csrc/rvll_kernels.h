@@ -1,0 +1,59 @@
+// rvll_kernels.h — launch interface between the C-ABI host code (rvll_api.hip)
+// and the gfx950 kernels (rvll_kernels.hip).  Internal; not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "rvll.h"
+
+namespace rvll {
+
+constexpr int kThreads = 256;          // 4 wave64 per workgroup, one per SIMD
+constexpr int kWave    = 64;
+constexpr int kPlanetFields = 8;       // per (point, planet) scalars kept in LDS
+constexpr int kMaxPointsPerBlock = 32;
+
+// Everything the fused log-L kernel needs; passed by value (kernarg segment).
+struct LoglikeArgs {
+    // batch
+    const double* theta;     // [B, D] row-major
+    double*       logL;      // [B]
+    int32_t*      flags;     // [B]
+    long long     B;
+    // resident epoch table (SoA, reference concatenation order)
+    const double*  t;        // [Ne]
+    const double*  y;        // [Ne]
+    const double*  s2;       // [Ne]  svrad^2
+    const int32_t* inst;     // [Ne]
+    const double*  linpar;   // [nlin, Ne] or nullptr
+    int Ne;
+    // layout (device copies of the ABI structs)
+    const rvll_planet* planets;   // [Np]
+    const rvll_inst*   insts;     // [Ni]
+    const rvll_slot*   linslots;  // [nlin]
+    int D, Np, Ni, nlin;
+    int has_jitter, has_drift, tref_from_data;
+    rvll_slot drift[4];
+    rvll_slot tref;
+    double tol;
+    int    itmax;
+    // geometry
+    int    PB;               // live points per workgroup
+    int    CH;               // contribution slots in LDS (items per chunk)
+    double cte;              // -0.5 * Ne * log(2*pi)
+};
+
+size_t loglike_lds_bytes(const LoglikeArgs& a);
+hipError_t launch_loglike(const LoglikeArgs& a, hipStream_t stream);
+
+struct PriorArgs {
+    const double* cube;      // [B, D]
+    double*       theta;     // [B, D]
+    long long     B;
+    int           D;
+    const rvll_prior* priors;  // [D] device copy; table pointers are device pointers
+};
+hipError_t launch_prior(const PriorArgs& a, hipStream_t stream);
+
+hipError_t launch_fill_cube(double* cube, long long n, uint64_t seed, hipStream_t stream);
+
+}  // namespace rvll

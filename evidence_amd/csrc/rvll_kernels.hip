@@ -1,0 +1,488 @@
+// rvll_kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the RV
+// log-likelihood hot path.  Compiled with -ffp-contract=off (see rvll_math.h).
+//
+//   loglike_kernel  fuses, for a whole batch of live points,
+//       evidence/rvmodel/__init__.py:173-217  log_likelihood
+//       evidence/rvmodel/__init__.py:343-385  kep_rv
+//       evidence/rvmodel/__init__.py:388-463  modelk
+//       evidence/rvmodel/trueanomaly.c:8-41   trueanomaly (Newton, tol 1e-4)
+//       evidence/rvmodel/__init__.py:222-273  drift
+//       evidence/rvmodel/__init__.py:59-80    logL
+//   into one launch: one thread per (live point, epoch) pair, Kepler iteration and
+//   sin/cos in registers, per-point reduction through LDS + wave shuffles.
+//
+//   prior_kernel    evidence/priors.py .ppf of each distribution, one thread per
+//       (live point, parameter).
+//
+// Roofline: this path is fp64-VALU bound (software sin/cos, IEEE division); HBM
+// traffic is theta in + log-L out (+ the epoch table, L2-resident).  No MFMA: there
+// is no contraction here.
+#include "rvll_kernels.h"
+#include "rvll_math.h"
+
+namespace rvll {
+
+namespace {
+
+constexpr double kTwoPi = 6.283185307179586476925286766559;   // fl(2*pi), as 2*np.pi
+
+__device__ __forceinline__ double slot_get(const rvll_slot& s, const double* th)
+{
+    return s.idx >= 0 ? th[s.idx] : s.val;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// LDS carve-up, all in units of doubles except the int tail.
+struct Carve {
+    int theta, pp, ins, dr, lin, acc, contrib, ints, total_doubles;
+};
+__host__ __device__ inline Carve carve(int PB, int D, int Np, int Ni, int nlin, int CH)
+{
+    Carve c;
+    int o = 0;
+    c.theta = o;   o += PB * D;
+    o = (o + 1) & ~1;                       // 16-byte align the double2-read regions
+    c.pp = o;      o += PB * Np * kPlanetFields;
+    c.ins = o;     o += PB * Ni * 2;
+    c.dr = o;      o += PB * 6;
+    c.lin = o;     o += PB * nlin;
+    c.acc = o;     o += PB;
+    o = (o + 1) & ~1;
+    c.contrib = o; o += CH;
+    c.ints = o;    // ints: nfail[1] pad[1] pflags[PB] anyfail[PB] jfail[PB*Np]
+    const int nints = 2 + 2 * PB + PB * Np;
+    o += (nints + 1) / 2;
+    c.total_doubles = o;
+    return c;
+}
+
+// Per-block LDS views handed to eval_item (plain pointers; the kernel arguments
+// themselves are passed by reference so they stay in the scalar kernarg segment).
+struct ItemCtx {
+    const double* pp;
+    const double* ins;
+    const double* dr;
+    const double* lin;
+    int* nfail;
+    int* anyfail;
+    int* jfail;
+};
+
+// One (point, epoch) item: returns ln sqrt(var) + res^2 / (2 var).
+__device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx& cx, int pl, int j)
+{
+    const double t  = a.t[j];
+    const double y  = a.y[j];
+    const double s2 = a.s2[j];
+    const int    in = a.inst[j];
+
+    const double2 oj = *reinterpret_cast<const double2*>(cx.ins + (pl * a.Ni + in) * 2);
+    double rvm = 0. + oj.x;                                   // rvmodel:187
+    const double var = s2 + oj.y;                             // rvmodel:189-192 (oj.y = jitter^2 or 0)
+
+    if (a.Np > 0) {
+        const bool point_failed = cx.anyfail[pl] != 0;
+        double ksum = 0.;
+        for (int ip = 0; ip < a.Np; ++ip) {
+            const double* P = cx.pp + (pl * a.Np + ip) * kPlanetFields;
+            const double2 p01 = *reinterpret_cast<const double2*>(P);       // w, epoch
+            const double2 p23 = *reinterpret_cast<const double2*>(P + 2);   // ma0, ec
+            const double2 p45 = *reinterpret_cast<const double2*>(P + 4);   // A=K cos w, Bq=K q sin w
+            const double  C0  = P[6];                                       // K e cos w
+            const double ec = p23.y;
+            double rv;
+            if (point_failed && j >= cx.jfail[pl * a.Np + ip]) {
+                rv = p45.x + C0;            // nu left at 0 (rvmodel:488, trueanomaly.c:32-33)
+            } else {
+                // mean anomaly, rvmodel:459 — two roundings in (t-epoch), then mul, then add
+                const double M = p01.x * (t - p01.y) + p23.x;
+                // Newton, trueanomaly.c:17-33 — op-by-op, no contraction
+                double E = M, s, c, dE;
+                int steps = 0;
+                do {
+                    sincos_f64(E, s, c);
+                    const double f  = E - ec * s - M;
+                    const double fp = 1 - ec * c;
+                    const double En = E - f / fp;
+                    dE = En - E;
+                    E = En;
+                    ++steps;
+                } while (fabs(dE) > a.tol && steps < a.itmax);
+                if (steps >= a.itmax) {
+                    atomicMin(&cx.jfail[pl * a.Np + ip], j);
+                    atomicOr(&cx.anyfail[pl], 1);
+                    atomicOr(cx.nfail, 1);
+                    rv = p45.x + C0;
+                } else {
+                    // (s, c) are at the previous iterate; the accepted step |dE| <= tol:
+                    // rotate instead of a third range reduction.
+                    if (a.tol <= 1e-3) rotate_small(dE, s, c);
+                    else               sincos_f64(E, s, c);
+                    // K (cos(nu+w) + e cos w) with cos nu = (cos E - e)/(1 - e cos E),
+                    // sin nu = sqrt(1-e^2) sin E/(1 - e cos E)  == trueanomaly.c:36 + rvmodel:463
+                    const double den = __builtin_fma(-ec, c, 1.0);
+                    const double num = __builtin_fma(p45.x, c - ec, -(p45.y * s));
+                    rv = num / den + C0;
+                }
+            }
+            ksum += rv;                                                     // rvmodel:383
+        }
+        rvm += ksum;                                                        // rvmodel:199
+    }
+
+    if (a.has_drift) {                                                      // rvmodel:242-271
+        const double* d = cx.dr + pl * 6;
+        const double tt = (t - d[4]) / 365.25;
+        const double t2 = tt * tt;
+        rvm += d[0] * tt + d[1] * t2 + d[2] * (t2 * tt) + d[3] * (t2 * t2);
+    }
+    for (int k = 0; k < a.nlin; ++k)                                        // rvmodel:210-212
+        rvm += cx.lin[pl * a.nlin + k] * a.linpar[(size_t)k * a.Ne + j];
+
+    const double res = y - rvm;                                             // rvmodel:215
+    return 0.5 * log(var) + res * res / (2 * var);                          // rvmodel:80
+}
+
+__global__ __launch_bounds__(kThreads)
+void loglike_kernel(const LoglikeArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const Carve cv = carve(a.PB, a.D, a.Np, a.Ni, a.nlin, a.CH);
+    double* theta_s = smem + cv.theta;
+    double* pp      = smem + cv.pp;
+    double* ins     = smem + cv.ins;
+    double* dr      = smem + cv.dr;
+    double* lin     = smem + cv.lin;
+    double* acc     = smem + cv.acc;
+    double* contrib = smem + cv.contrib;
+    int*    ints    = reinterpret_cast<int*>(smem + cv.ints);
+    int*    nfail   = ints;
+    int*    pflags  = ints + 2;
+    int*    anyfail = pflags + a.PB;
+    int*    jfail   = anyfail + a.PB;
+
+    const int tid  = threadIdx.x;
+    const int lane = tid & (kWave - 1);
+    const int wave = tid >> 6;
+    const long long p0 = (long long)blockIdx.x * a.PB;
+    const int npts = (int)min((long long)a.PB, a.B - p0);
+    if (npts <= 0) return;
+
+    // 1. stage this block's theta rows (one contiguous, coalesced span) + init
+    {
+        const double* src = a.theta + p0 * a.D;
+        for (int i = tid; i < npts * a.D; i += kThreads) theta_s[i] = src[i];
+        for (int i = tid; i < npts; i += kThreads) { acc[i] = 0.; pflags[i] = 0; anyfail[i] = 0; }
+        for (int i = tid; i < npts * a.Np; i += kThreads) jfail[i] = 0x7fffffff;
+        if (tid == 0) nfail[0] = 0;
+    }
+    __syncthreads();
+
+    // 2. decode per-point scalars once (rvmodel:412-456, :181-192, :242-260)
+    {
+        const int per = a.Np + 1;
+        for (int wk = tid; wk < npts * per; wk += kThreads) {
+            const int pl = wk / per;
+            const int k  = wk - pl * per;
+            const double* th = theta_s + pl * a.D;
+            if (k < a.Np) {
+                const rvll_planet& d = a.planets[k];
+                const double kraw = slot_get(d.k, th);
+                const double praw = slot_get(d.p, th);
+                const double K = d.k_kind == RVLL_K_LOGK1 ? exp(kraw) : kraw;
+                const double Pd = d.p_kind == RVLL_P_LOGPERIOD ? exp(praw) : praw;
+                const double e1 = slot_get(d.e1, th);
+                const double e2 = slot_get(d.e2, th);
+                double ecc, omega;
+                if (d.ecc_kind == RVLL_ECC_SECOS_SESIN) {
+                    ecc = e1 * e1 + e2 * e2;
+                    omega = atan2(e2, e1);
+                    if (ecc > 1) atomicOr(&pflags[pl], RVLL_FLAG_INVALID_ORBIT);
+                } else if (d.ecc_kind == RVLL_ECC_ECOS_ESIN) {
+                    ecc = sqrt(e1 * e1 + e2 * e2);
+                    omega = atan2(e2, e1);
+                    if (ecc > 1) atomicOr(&pflags[pl], RVLL_FLAG_INVALID_ORBIT);
+                } else {
+                    ecc = e1;
+                    omega = e2;
+                }
+                const double anom = slot_get(d.anom, th);
+                const double ma0 = d.anom_kind == RVLL_ANOM_ML0 ? anom - omega : anom;
+                const double ec = ecc > 0.99 ? 0.99 : ecc;                  // trueanomaly.c:11-12
+                double so, co;
+                sincos_f64(omega, so, co);
+                const double q = sqrt((1. - ec) * (1. + ec));
+                double* P = pp + (pl * a.Np + k) * kPlanetFields;
+                P[0] = kTwoPi / Pd;
+                P[1] = slot_get(d.epoch, th);
+                P[2] = ma0;
+                P[3] = ec;
+                P[4] = K * co;
+                P[5] = K * q * so;
+                P[6] = K * (ecc * co);
+                P[7] = 0.;
+            } else {
+                for (int i = 0; i < a.Ni; ++i) {
+                    const rvll_inst& d = a.insts[i];
+                    ins[(pl * a.Ni + i) * 2] = slot_get(d.offset, th);
+                    double j2 = 0.;
+                    if (a.has_jitter) { const double jit = slot_get(d.jitter, th); j2 = jit * jit; }
+                    ins[(pl * a.Ni + i) * 2 + 1] = j2;
+                }
+                if (a.has_drift) {
+                    double* d = dr + pl * 6;
+                    d[0] = slot_get(a.drift[0], th);
+                    d[1] = slot_get(a.drift[1], th);
+                    d[2] = slot_get(a.drift[2], th);
+                    d[3] = slot_get(a.drift[3], th);
+                    d[4] = a.tref_from_data ? a.t[0] : slot_get(a.tref, th);
+                    d[5] = 0.;
+                }
+                for (int k2 = 0; k2 < a.nlin; ++k2) lin[pl * a.nlin + k2] = slot_get(a.linslots[k2], th);
+            }
+        }
+    }
+    __syncthreads();
+
+    // 3. items: flattened (point, epoch) pairs of this block, CH at a time
+    const ItemCtx cx{pp, ins, dr, lin, nfail, anyfail, jfail};
+    const int nitems = npts * a.Ne;
+    for (int base = 0; base < nitems; base += a.CH) {
+        const int cend = min(base + a.CH, nitems);
+        for (int i = base + tid; i < cend; i += kThreads) {
+            const int pl = i / a.Ne;
+            const int j  = i - pl * a.Ne;
+            contrib[i - base] = eval_item(a, cx, pl, j);
+        }
+        __syncthreads();
+        // 3b. rare: a solve hit itmax.  The reference aborts that planet's array there
+        // and leaves nu = 0 from that epoch on; redo the affected points' items now that
+        // the first failing epoch per (point, planet) is known.
+        if (nfail[0] != 0) {
+            for (int i = base + tid; i < cend; i += kThreads) {
+                const int pl = i / a.Ne;
+                if (anyfail[pl]) contrib[i - base] = eval_item(a, cx, pl, i - pl * a.Ne);
+            }
+            __syncthreads();
+        }
+        // 3c. per-point partial sums of this chunk, fixed order (deterministic)
+        const int pl_lo = base / a.Ne;
+        const int pl_hi = (cend - 1) / a.Ne;
+        for (int pl = pl_lo + wave; pl <= pl_hi; pl += kThreads / kWave) {
+            const int lo = max(base, pl * a.Ne);
+            const int hi = min(cend, (pl + 1) * a.Ne);
+            double v = 0.;
+            for (int i = lo + lane; i < hi; i += kWave) v += contrib[i - base];
+            v = wave_sum(v);
+            if (lane == 0) acc[pl] += v;
+        }
+        __syncthreads();
+    }
+
+    // 4. one log-L per live point
+    for (int pl = tid; pl < npts; pl += kThreads) {
+        int f = pflags[pl];
+        if (anyfail[pl]) f |= RVLL_FLAG_NONCONVERGED;
+        const bool invalid = (f & RVLL_FLAG_INVALID_ORBIT) != 0 && a.Np > 0;
+        a.logL[p0 + pl] = invalid ? -1e30 : a.cte - acc[pl];              // rvmodel:203, :78-80
+        if (a.flags) a.flags[p0 + pl] = f;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// prior transform
+// ---------------------------------------------------------------------------
+
+// Inverse normal CDF, Wichura's AS241 (PPND16), relative accuracy ~1e-16.
+__device__ double ndtri_f64(double p)
+{
+    if (!(p > 0.)) return p == 0. ? -INFINITY : NAN;
+    if (!(p < 1.)) return p == 1. ? INFINITY : NAN;
+    const double q = p - 0.5;
+    if (fabs(q) <= 0.425) {
+        const double r = 0.180625 - q * q;
+        double num = 2509.0809287301226727;
+        num = __builtin_fma(num, r, 33430.575583588128105);
+        num = __builtin_fma(num, r, 67265.770927008700853);
+        num = __builtin_fma(num, r, 45921.953931549871457);
+        num = __builtin_fma(num, r, 13731.693765509461125);
+        num = __builtin_fma(num, r, 1971.5909503065514427);
+        num = __builtin_fma(num, r, 133.14166789178437745);
+        num = __builtin_fma(num, r, 3.387132872796366608);
+        double den = 5226.495278852545925;
+        den = __builtin_fma(den, r, 28729.085735721942674);
+        den = __builtin_fma(den, r, 39307.89580009271061);
+        den = __builtin_fma(den, r, 21213.794301586595867);
+        den = __builtin_fma(den, r, 5394.1960214247511077);
+        den = __builtin_fma(den, r, 687.1870074920579083);
+        den = __builtin_fma(den, r, 42.313330701600911252);
+        den = __builtin_fma(den, r, 1.0);
+        return q * num / den;
+    }
+    double r = q < 0. ? p : 1. - p;
+    r = sqrt(-log(r));
+    double val;
+    if (r <= 5.) {
+        r -= 1.6;
+        double num = 7.7454501427834140764e-4;
+        num = __builtin_fma(num, r, 0.0227238449892691845833);
+        num = __builtin_fma(num, r, 0.24178072517745061177);
+        num = __builtin_fma(num, r, 1.27045825245236838258);
+        num = __builtin_fma(num, r, 3.64784832476320460504);
+        num = __builtin_fma(num, r, 5.7694972214606914055);
+        num = __builtin_fma(num, r, 4.6303378461565452959);
+        num = __builtin_fma(num, r, 1.42343711074968357734);
+        double den = 1.05075007164441684324e-9;
+        den = __builtin_fma(den, r, 5.475938084995344946e-4);
+        den = __builtin_fma(den, r, 0.0151986665636164571966);
+        den = __builtin_fma(den, r, 0.14810397642748007459);
+        den = __builtin_fma(den, r, 0.68976733498510000455);
+        den = __builtin_fma(den, r, 1.6763848301838038494);
+        den = __builtin_fma(den, r, 2.05319162663775882187);
+        den = __builtin_fma(den, r, 1.0);
+        val = num / den;
+    } else {
+        r -= 5.;
+        double num = 2.01033439929228813265e-7;
+        num = __builtin_fma(num, r, 2.71155556874348757815e-5);
+        num = __builtin_fma(num, r, 0.0012426609473880784386);
+        num = __builtin_fma(num, r, 0.026532189526576123093);
+        num = __builtin_fma(num, r, 0.29656057182850489123);
+        num = __builtin_fma(num, r, 1.7848265399172913358);
+        num = __builtin_fma(num, r, 5.4637849111641143699);
+        num = __builtin_fma(num, r, 6.6579046435011037772);
+        double den = 2.04426310338993978564e-15;
+        den = __builtin_fma(den, r, 1.4215117583164458887e-7);
+        den = __builtin_fma(den, r, 1.8463183175100546818e-5);
+        den = __builtin_fma(den, r, 7.868691311456132591e-4);
+        den = __builtin_fma(den, r, 0.0148753612908506148525);
+        den = __builtin_fma(den, r, 0.13692988092273580531);
+        den = __builtin_fma(den, r, 0.59983220655588793769);
+        den = __builtin_fma(den, r, 1.0);
+        val = num / den;
+    }
+    return q < 0. ? -val : val;
+}
+
+// Piecewise-linear inverse CDF on a host-built grid; the semantics of
+// scipy.interpolate.interp1d(cdf, x)(q) (which evaluates 1-D linear tables through
+// numpy.interp) as used by priors.py:118-124 and friends.
+__device__ double table_ppf(const rvll_prior& pr, double q)
+{
+    const int n = pr.table_n;
+    const double* xp = pr.table_cdf;
+    const double* fp = pr.table_x;
+    const bool wrapped = pr.args[2] != 0.;
+    if (wrapped) {                       // scipy rv_continuous.ppf front end
+        if (q == 0.) return pr.args[0];
+        if (q == 1.) return pr.args[1];
+        if (!(q > 0. && q < 1.)) return NAN;
+    }
+    if (!(q >= xp[0] && q <= xp[n - 1])) return NAN;   // interp1d raises ValueError here
+    // last j with xp[j] <= q
+    int lo = 0, hi = n;                  // invariant: xp[lo] <= q, (hi == n or xp[hi] > q)
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (xp[mid] <= q) lo = mid; else hi = mid;
+    }
+    const int j = lo;
+    double y;
+    if (j == n - 1) y = fp[j];
+    else if (xp[j] == q) y = fp[j];
+    else {
+        const double slope = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
+        y = slope * (q - xp[j]) + fp[j];
+        if (isnan(y)) {
+            y = slope * (q - xp[j + 1]) + fp[j + 1];
+            if (isnan(y) && fp[j] == fp[j + 1]) y = fp[j];
+        }
+    }
+    return pr.table_post ? pow(10., y) : y;
+}
+
+__global__ __launch_bounds__(kThreads)
+void prior_kernel(const PriorArgs a)
+{
+    const long long n = a.B * a.D;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n;
+         i += (long long)gridDim.x * kThreads) {
+        const int d = (int)(i % a.D);
+        const rvll_prior& pr = a.priors[d];
+        const double q = a.cube[i];
+        double v;
+        switch (pr.kind) {
+        case RVLL_PRIOR_UNIFORM:             // priors.py:41-42
+            v = pr.args[0] + (pr.args[1] - pr.args[0]) * q; break;
+        case RVLL_PRIOR_JEFFREYS:            // priors.py:62-63
+            v = pr.args[0] * pow(pr.args[1] / pr.args[0], q); break;
+        case RVLL_PRIOR_MODJEFFREYS:         // priors.py:82-83
+            v = pr.args[0] * pow(1 + pr.args[1] / pr.args[0], q) - pr.args[0]; break;
+        case RVLL_PRIOR_UNIFORMFREQUENCY:    // priors.py:100-101
+            v = pr.args[0] / (1 - q * (pr.args[1] - pr.args[0]) / pr.args[1]); break;
+        case RVLL_PRIOR_NORMAL:              // stats.norm.ppf: loc + scale*ndtri(q)
+            v = (q >= 0. && q <= 1.) ? ndtri_f64(q) * pr.args[1] + pr.args[0] : NAN; break;
+        case RVLL_PRIOR_LOGNORMAL:           // stats.lognorm.ppf: loc + scale*exp(s*ndtri(q))
+            v = (q >= 0. && q <= 1.) ? exp(pr.args[0] * ndtri_f64(q)) * pr.args[2] + pr.args[1] : NAN; break;
+        case RVLL_PRIOR_TRUNCRAYLEIGH: {     // priors.py:249-252
+            const double sg = pr.args[0], xm = pr.args[1];
+            const double A = 1 - exp(-(xm * xm) / (2 * (sg * sg)));
+            v = sqrt(-2 * (sg * sg) * log(1 - (q * A))); break; }
+        case RVLL_PRIOR_TABLE:
+            v = table_ppf(pr, q); break;
+        default:
+            v = NAN; break;
+        }
+        a.theta[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(kThreads)
+void fill_cube_kernel(double* cube, long long n, uint64_t seed)
+{
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n;
+         i += (long long)gridDim.x * kThreads)
+        cube[i] = uniform01(seed, (uint64_t)i);
+}
+
+}  // namespace
+
+size_t loglike_lds_bytes(const LoglikeArgs& a)
+{
+    return (size_t)carve(a.PB, a.D, a.Np, a.Ni, a.nlin, a.CH).total_doubles * sizeof(double);
+}
+
+hipError_t launch_loglike(const LoglikeArgs& a, hipStream_t stream)
+{
+    if (a.B <= 0) return hipSuccess;
+    const long long blocks = (a.B + a.PB - 1) / a.PB;
+    const size_t lds = loglike_lds_bytes(a);
+    hipLaunchKernelGGL(loglike_kernel, dim3((unsigned)blocks), dim3(kThreads), lds, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_prior(const PriorArgs& a, hipStream_t stream)
+{
+    const long long n = a.B * a.D;
+    if (n <= 0) return hipSuccess;
+    long long blocks = (n + kThreads - 1) / kThreads;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(prior_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_cube(double* cube, long long n, uint64_t seed, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    long long blocks = (n + kThreads - 1) / kThreads;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(fill_cube_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, cube, n, seed);
+    return hipGetLastError();
+}
+
+}  // namespace rvll

@@ -1,0 +1,210 @@
+"""GpuRVModel — the host-side mirror of the reference's RVModel for the hot path.
+
+Duck-types what the reference's sampler wrappers use from a model
+(evidence/polychord/__init__.py:92,100-102,216-218; evidence/ultranest/__init__.py:93):
+`.parnames` (sorted), `.log_likelihood(x)`, `.datadict`, `.fixedpardict`, `.nplanets`,
+plus the batched forms the GPU exists for.  Every evaluation goes through the C-ABI
+(include/rvll.h) into the HIP kernels; there is no host implementation.
+"""
+import ctypes as C
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+from . import _abi
+from .data import EpochTable
+from .layout import compile_layout
+from .priors import PriorSpec
+
+
+class GpuRVModel:
+    """RV model with its epoch table resident on one MI355X.
+
+    Parameters follow RVModel.__init__ (evidence/rvmodel/__init__.py:94-154):
+    fixedpardict  {name: value} of fixed parameters
+    datadict      {instrument: {'data': table with rjd|jdb, vrad, svrad}}  (or an EpochTable)
+    parnames      names of the free parameters; theta is ordered as sorted(parnames)
+    linpar_dict   optional {key: series[Ne]} for `linpar_{key}` terms (rvmodel:131-136,210-212)
+    priordict     optional {parname: PriorSpec}; enables prior_transform*
+    device        HIP device index (default: current device)
+    """
+
+    def __init__(self, fixedpardict: Dict[str, float], datadict, parnames: Sequence[str],
+                 linpar_dict: Optional[Dict[str, np.ndarray]] = None,
+                 priordict: Optional[Dict[str, PriorSpec]] = None, device: int = -1):
+        self._lib = _abi.load()          # raises RvllLibraryError when the HIP library is absent
+        self._h = _abi.Handle()
+        self.fixedpardict = dict(fixedpardict)
+        self.table = datadict if isinstance(datadict, EpochTable) else EpochTable.from_datadict(datadict)
+        self.datadict = datadict if not isinstance(datadict, EpochTable) else self.table.to_datadict()
+        self.insts = list(self.table.insts)
+        self.linpar_dict = dict(linpar_dict) if linpar_dict else {}
+        self.layout = compile_layout(parnames, self.fixedpardict, self.insts, list(self.linpar_dict))
+        self.parnames = list(self.layout.parnames)
+        self.nplanets = self.layout.nplanets
+        self.drift_in_model = self.layout.has_drift
+        self.linpar_in_model = self.layout.has_linpar
+        self.jitter_in_model = self.layout.has_jitter
+        self.time, self.vrad, self.svrad = self.table.time, self.table.vrad, self.table.svrad
+        self.model_path = None
+
+        series = None
+        if self.layout.linpar_names:
+            series = np.ascontiguousarray(
+                np.stack([np.asarray(self.linpar_dict[k], dtype=np.float64) for k in self.layout.linpar_names]))
+            if series.shape != (len(self.layout.linpar_names), self.table.n_epochs):
+                raise ValueError("each linpar series must have one value per epoch")
+        self._series = series
+        layout_c, self._layout_keep = self.layout.to_c()
+        _abi.check(self._lib.rvll_create(
+            C.byref(layout_c), _abi.as_dp(self.table.time), _abi.as_dp(self.table.vrad),
+            _abi.as_dp(self.table.svrad), _abi.as_ip(self.table.inst_id), self.table.n_epochs,
+            _abi.as_dp(series) if series is not None else None, int(device), C.byref(self._h)))
+        self.priordict = None
+        if priordict is not None:
+            self.set_priors(priordict)
+
+    # ---- lifetime ---------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.rvll_destroy(self._h)
+            self._h = _abi.Handle()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def ndim(self):
+        return len(self.parnames)
+
+    # ---- priors -------------------------------------------------------------------------
+    def set_priors(self, priordict: Dict[str, PriorSpec]):
+        """priordict[name] for every free parameter (evidence/polychord/__init__.py:152)."""
+        specs = []
+        for name in self.parnames:
+            if name not in priordict:
+                raise KeyError(name)
+            specs.append(priordict[name])
+        arr = (_abi.Prior * max(1, len(specs)))()
+        for i, s in enumerate(specs):
+            arr[i] = s.to_c()
+        _abi.check(self._lib.rvll_set_priors(self._h, arr, len(specs)))
+        self.priordict = dict(priordict)
+
+    # ---- log-likelihood --------------------------------------------------------------------
+    def _theta2d(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        if x.ndim != 2 or x.shape[1] != self.ndim:
+            raise ValueError(f"expected an array of shape (n, {self.ndim}), got {x.shape}")
+        return x
+
+    def log_likelihood_batch(self, X, return_flags=False):
+        """log-L of every row of X[n, ndim] -> float64[n] (one fused kernel launch)."""
+        X = self._theta2d(X)
+        n = X.shape[0]
+        out = np.empty(n, dtype=np.float64)
+        flags = np.zeros(n, dtype=np.int32)
+        _abi.check(self._lib.rvll_loglike_batch(self._h, _abi.as_dp(X), n, _abi.as_dp(out), _abi.as_ip(flags)))
+        return (out, flags) if return_flags else out
+
+    def log_likelihood(self, x):
+        """Scalar form, same signature as RVModel.log_likelihood (rvmodel/__init__.py:157)."""
+        x = np.asarray(x, dtype=np.float64).reshape(1, -1)
+        return float(self.log_likelihood_batch(x)[0])
+
+    # ---- prior transform --------------------------------------------------------------------
+    def prior_transform_batch(self, cubes):
+        cubes = self._theta2d(cubes)
+        out = np.empty_like(cubes)
+        _abi.check(self._lib.rvll_prior_batch(self._h, _abi.as_dp(cubes), cubes.shape[0], _abi.as_dp(out)))
+        return out
+
+    def prior_transform(self, cube):
+        cube = np.asarray(cube, dtype=np.float64)
+        return self.prior_transform_batch(cube.reshape(1, -1))[0].reshape(cube.shape)
+
+    def prior_loglike_batch(self, cubes, return_flags=False):
+        """Fused prior(cube) -> theta -> log-L: one upload, two launches, one download."""
+        cubes = self._theta2d(cubes)
+        n = cubes.shape[0]
+        theta = np.empty_like(cubes)
+        out = np.empty(n, dtype=np.float64)
+        flags = np.zeros(n, dtype=np.int32)
+        _abi.check(self._lib.rvll_prior_loglike_batch(self._h, _abi.as_dp(cubes), n, _abi.as_dp(theta),
+                                                      _abi.as_dp(out), _abi.as_ip(flags)))
+        return (theta, out, flags) if return_flags else (theta, out)
+
+    # ---- device-resident forms (bench / multi-GPU) ----------------------------------------------
+    def dev_reserve(self, n):
+        _abi.check(self._lib.rvll_dev_reserve(self._h, int(n)))
+
+    def dev_upload_theta(self, X):
+        X = self._theta2d(X)
+        _abi.check(self._lib.rvll_dev_upload_theta(self._h, _abi.as_dp(X), X.shape[0]))
+
+    def dev_upload_cube(self, cubes):
+        cubes = self._theta2d(cubes)
+        _abi.check(self._lib.rvll_dev_upload_cube(self._h, _abi.as_dp(cubes), cubes.shape[0]))
+
+    def dev_fill_cube(self, n, seed):
+        _abi.check(self._lib.rvll_dev_fill_cube(self._h, int(n), int(seed)))
+
+    def dev_prior(self, n):
+        _abi.check(self._lib.rvll_dev_prior(self._h, int(n)))
+
+    def dev_loglike(self, n):
+        _abi.check(self._lib.rvll_dev_loglike(self._h, int(n)))
+
+    def dev_sync(self):
+        _abi.check(self._lib.rvll_dev_sync(self._h))
+
+    def dev_download(self, n, theta=False, logl=True, flags=False):
+        n = int(n)
+        th = np.empty((n, self.ndim), dtype=np.float64) if theta else None
+        ll = np.empty(n, dtype=np.float64) if logl else None
+        fl = np.empty(n, dtype=np.int32) if flags else None
+        _abi.check(self._lib.rvll_dev_download(
+            self._h, n, _abi.as_dp(th) if theta else None, _abi.as_dp(ll) if logl else None,
+            _abi.as_ip(fl) if flags else None))
+        return th, ll, fl
+
+    def dev_time_loglike(self, n, warmup=3, iters=20):
+        t = _abi.Timing()
+        _abi.check(self._lib.rvll_dev_time_loglike(self._h, int(n), int(warmup), int(iters), C.byref(t)))
+        return {f: getattr(t, f) for f, _ in _abi.Timing._fields_}
+
+    def set_points_per_block(self, pb):
+        _abi.check(self._lib.rvll_set_points_per_block(self._h, int(pb)))
+
+    # ---- multi-GPU ----------------------------------------------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        buf = (C.c_ubyte * _abi.COMM_ID_BYTES)()
+        _abi.check(_abi.load().rvll_comm_unique_id(buf))
+        return bytes(buf)
+
+    def comm_init(self, comm_id: bytes, nranks: int, rank: int):
+        if len(comm_id) != _abi.COMM_ID_BYTES:
+            raise ValueError("comm id must be 128 bytes")
+        buf = (C.c_ubyte * _abi.COMM_ID_BYTES).from_buffer_copy(comm_id)
+        _abi.check(self._lib.rvll_comm_init(self._h, buf, int(nranks), int(rank)))
+
+    def allgather_logl(self, n_local):
+        _abi.check(self._lib.rvll_allgather_logl(self._h, int(n_local)))
+
+    def download_gathered(self, n_total):
+        out = np.empty(int(n_total), dtype=np.float64)
+        _abi.check(self._lib.rvll_download_gathered(self._h, int(n_total), _abi.as_dp(out)))
+        return out
+
+    def comm_destroy(self):
+        _abi.check(self._lib.rvll_comm_destroy(self._h))

@@ -1,0 +1,247 @@
+/*
+ * rvll.h — C-ABI of the MI355X-native RV log-likelihood engine ("rvll").
+ *
+ * This is the drop-in boundary for the one hot path of nicochunger/evidence:
+ * the per-live-point Keplerian RV forward model + Gaussian log-likelihood and
+ * the unit-cube -> theta prior transform.  Everything here is extern "C",
+ * plain pointers and sizes; the caller owns every host buffer, the library
+ * owns device memory behind an opaque handle.  One handle = one device + its
+ * own HIP streams.  A handle is not thread-safe; distinct handles are
+ * independent.
+ *
+ * What each entry point replaces in the reference (paths relative to the
+ * reference checkout):
+ *
+ *   rvll_create              evidence/rvmodel/__init__.py:23-57,94-154
+ *                            (BaseModel/RVModel.__init__: concatenated epoch
+ *                            table, instrument ids, planet count, model flags)
+ *   rvll_loglike_batch       evidence/rvmodel/__init__.py:157-219 (log_likelihood)
+ *                            -> :343-385 (kep_rv) -> :388-463 (modelk)
+ *                            -> :466-494 (true_anomaly) -> rvmodel/trueanomaly.c:8-41
+ *                            -> :222-273 (drift) -> :59-80 (logL)
+ *                            i.e. it is the batched form of the existing FFI
+ *                            `int trueanomaly(double*,int,double,double*,int,double)`
+ *                            (rvmodel/trueanomaly.h:4) fused with its caller.
+ *   rvll_set_priors /
+ *   rvll_prior_batch         evidence/priors.py:22-460 (.ppf of every
+ *                            distribution) as called from
+ *                            evidence/polychord/__init__.py:130-162 and
+ *                            evidence/ultranest/__init__.py:125-137
+ *   rvll_prior_loglike_batch prior(cube) followed by loglike(theta), one launch
+ *   rvll_comm_* / rvll_allgather_logl
+ *                            replaces the MPI fan-out owned by the third-party
+ *                            samplers (evidence/polychord/__init__.py:21-29,
+ *                            176-199) with one RCCL all-gather of per-shard log-L
+ *
+ * Error convention: every function returns 0 on success or a negative
+ * RVLL_E_* code; rvll_last_error() returns a human-readable message for the
+ * calling thread's last failure.  Model-level conditions are NOT errors and
+ * follow the reference: an invalid orbit (ecc > 1 in the secos/sesin or
+ * ecos/esin parametrisation) gives log-L = -1e30
+ * (evidence/rvmodel/__init__.py:198-203,430-431,438-439).
+ */
+#ifndef RVLL_H
+#define RVLL_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RVLL_VERSION_MAJOR 0
+#define RVLL_VERSION_MINOR 1
+
+/* ---- error codes ------------------------------------------------------ */
+#define RVLL_OK             0
+#define RVLL_E_INVALID     -1   /* bad argument / inconsistent layout        */
+#define RVLL_E_NODEVICE    -2   /* no HIP device, or device index invalid    */
+#define RVLL_E_HIP         -3   /* a HIP runtime call failed                 */
+#define RVLL_E_NOMEM       -4   /* host or device allocation failed          */
+#define RVLL_E_NOPRIORS    -5   /* prior transform requested before set_priors */
+#define RVLL_E_RCCL        -6   /* RCCL missing or a collective failed       */
+#define RVLL_E_UNSUPPORTED -7   /* feature not available in this build       */
+
+/* ---- per-point flag bits written by the log-L kernels ------------------ */
+#define RVLL_FLAG_INVALID_ORBIT  1  /* ecc>1 in a derived parametrisation -> logL=-1e30 */
+#define RVLL_FLAG_NONCONVERGED   2  /* a Kepler solve hit itmax (trueanomaly.c:32-33 path) */
+
+/* ---- parameter slot: where a model scalar comes from ------------------- */
+/* idx >= 0 : free parameter, value = theta[idx]   (theta ordered as sorted(parnames),
+ *            evidence/rvmodel/__init__.py:43)
+ * idx <  0 : fixed parameter, value = val         (fixedpardict)              */
+typedef struct rvll_slot {
+    int32_t idx;
+    int32_t reserved;
+    double  val;
+} rvll_slot;
+
+/* parametrisation choices of modelk (evidence/rvmodel/__init__.py:412-456) */
+enum { RVLL_K_K1 = 0, RVLL_K_LOGK1 = 1 };                 /* :412-415 */
+enum { RVLL_P_PERIOD = 0, RVLL_P_LOGPERIOD = 1 };         /* :417-420 */
+enum { RVLL_ECC_DIRECT = 0,                               /* ecc, omega      :441-447 */
+       RVLL_ECC_SECOS_SESIN = 1,                          /* sqrt(e)cos/sin  :425-431 */
+       RVLL_ECC_ECOS_ESIN = 2 };                          /* e cos/sin       :433-439 */
+enum { RVLL_ANOM_MA0 = 0, RVLL_ANOM_ML0 = 1 };            /* :449-454 */
+
+typedef struct rvll_planet {
+    int32_t   k_kind;
+    int32_t   p_kind;
+    int32_t   ecc_kind;
+    int32_t   anom_kind;
+    rvll_slot k;        /* k1 | logk1                          */
+    rvll_slot p;        /* period | logperiod                  */
+    rvll_slot e1;       /* ecc   | secos | ecos                */
+    rvll_slot e2;       /* omega | sesin | esin                */
+    rvll_slot anom;     /* ma0 | ml0                           */
+    rvll_slot epoch;    /* planet{n}_epoch                     */
+} rvll_planet;
+
+typedef struct rvll_inst {
+    rvll_slot offset;   /* {inst}_offset  (rvmodel:187)                       */
+    rvll_slot jitter;   /* {inst}_jitter  (rvmodel:189-190); unused if !has_jitter */
+} rvll_inst;
+
+enum { RVLL_PREC_FP64 = 0 };   /* fp32 / mixed modes are a later-round row */
+
+typedef struct rvll_layout {
+    int32_t struct_size;       /* = sizeof(rvll_layout), ABI check            */
+    int32_t ndim;              /* D = number of free parameters               */
+    int32_t nplanets;          /* rvmodel:122-124                             */
+    int32_t ninst;             /* number of instruments (datadict keys)       */
+    int32_t has_jitter;        /* rvmodel:138-139                             */
+    int32_t has_drift;         /* rvmodel:128-129                             */
+    int32_t tref_from_data;    /* 1: tref = time[0] (rvmodel:259-260)         */
+    int32_t nlinpar;           /* number of linear-activity series (rvmodel:210-212) */
+    rvll_slot drift[4];        /* lin, quad, cub, quar (rvmodel:246-253)      */
+    rvll_slot tref;            /* drift_tref (rvmodel:257-258)                */
+    const rvll_planet* planets;   /* [nplanets]                               */
+    const rvll_inst*   insts;     /* [ninst]                                  */
+    const rvll_slot*   linpar;    /* [nlinpar] coefficients linpar_X          */
+    double  tol;               /* Newton stop rule, 1e-4 (rvmodel:466)        */
+    int32_t itmax;             /* 10000 (rvmodel:491)                         */
+    int32_t precision;         /* RVLL_PREC_*                                 */
+} rvll_layout;
+
+/* ---- priors ------------------------------------------------------------ */
+/* Kinds follow the names exported by evidence/priors.py:429-467.            */
+enum {
+    RVLL_PRIOR_UNIFORM = 0,          /* priors.py:41-42   args xmin,xmax     */
+    RVLL_PRIOR_JEFFREYS = 1,         /* :62-63            xmin,xmax          */
+    RVLL_PRIOR_MODJEFFREYS = 2,      /* :82-83            x0,xmax            */
+    RVLL_PRIOR_UNIFORMFREQUENCY = 3, /* :100-101          xmin,xmax          */
+    RVLL_PRIOR_NORMAL = 4,           /* :436 stats.norm   loc,scale          */
+    RVLL_PRIOR_LOGNORMAL = 5,        /* :437 stats.lognorm s,loc,scale       */
+    RVLL_PRIOR_TRUNCRAYLEIGH = 6,    /* :249-252          sigma,xmax         */
+    RVLL_PRIOR_TABLE = 7,            /* piecewise-linear inverse CDF on a host-built
+                                        grid: Binormal :118-124, AsymmetricNormal
+                                        :195-202, TruncatedUNormal :223-228,
+                                        PowerLaw :282-287, DoublePowerLaw :321-326,
+                                        Sine :349-354, Log10Normal :138-144.
+                                        args: lo,hi (values returned at q==0 / q==1),
+                                        flags                                 */
+    RVLL_PRIOR_BETA = 8,             /* :397-398 stats.beta.ppf   a,b         */
+    RVLL_PRIOR_GAMMA = 9,            /* :424-425 stats.gamma.ppf  alpha,beta  */
+    RVLL_PRIOR_ALPHA = 10,           /* :375-376 stats.alpha.ppf  a           */
+    RVLL_PRIOR_SORTED_UNIFORM = 11,  /* priors.py:462-467 (pypolychord)  a,b  */
+    RVLL_PRIOR_SORTED_LOGUNIFORM = 12,
+    RVLL_PRIOR__COUNT
+};
+
+#define RVLL_PRIOR_NARGS 6
+typedef struct rvll_prior {
+    int32_t kind;
+    int32_t group;             /* sorted priors: members of one group share an id >= 0 */
+    double  args[RVLL_PRIOR_NARGS];
+    const double* table_cdf;   /* RVLL_PRIOR_TABLE: sorted knots  [table_n]  */
+    const double* table_x;     /*                   values         [table_n]  */
+    int32_t table_n;
+    int32_t table_post;        /* 0: y ; 1: 10**y  (Log10Normal)              */
+} rvll_prior;
+
+/* ---- timing report of the device-resident benchmark -------------------- */
+typedef struct rvll_timing {
+    double kernel_ms_mean;     /* mean HIP-event time per launch             */
+    double kernel_ms_min;
+    double kernel_ms_median;
+    double total_ms;           /* first launch -> last launch complete       */
+    int64_t evals;             /* live points evaluated in total             */
+    int32_t launches;
+    int32_t points_per_block;  /* launch geometry actually used              */
+    int32_t blocks;
+    int32_t threads;
+} rvll_timing;
+
+typedef struct rvll_handle rvll_handle;
+
+/* ---- lifecycle ---------------------------------------------------------- */
+/* Upload the concatenated epoch table once.  Arrays are in the reference's
+ * concatenation order (instrument by instrument, evidence/rvmodel/__init__.py:50-55),
+ * NOT time-sorted.  inst[j] in [0,ninst).  linpar_series is [nlinpar][Ne]
+ * row-major or NULL.  device < 0 selects the current HIP device.            */
+int rvll_create(const rvll_layout* layout,
+                const double* time, const double* vrad, const double* svrad,
+                const int32_t* inst, int32_t n_epochs,
+                const double* linpar_series,
+                int32_t device, rvll_handle** out);
+int rvll_destroy(rvll_handle* h);
+
+/* ---- priors -------------------------------------------------------------- */
+int rvll_set_priors(rvll_handle* h, const rvll_prior* priors, int32_t ndim);
+
+/* ---- the hot calls (host buffers in, host buffers out) ------------------- */
+/* theta: [B, D] row-major.  logL: [B].  flags: [B] or NULL.                  */
+int rvll_loglike_batch(rvll_handle* h, const double* theta, int64_t B,
+                       double* logL, int32_t* flags);
+/* cube: [B, D] in [0,1].  theta: [B, D].                                     */
+int rvll_prior_batch(rvll_handle* h, const double* cube, int64_t B, double* theta);
+/* fused: one H2D, prior + log-L launches back to back, one D2H               */
+int rvll_prior_loglike_batch(rvll_handle* h, const double* cube, int64_t B,
+                             double* theta_out, double* logL, int32_t* flags);
+
+/* ---- device-resident forms (no PCIe inside; used by bench and multi-GPU) -- */
+/* Reserve device buffers for up to B points and copy theta (or cube) in.     */
+int rvll_dev_reserve(rvll_handle* h, int64_t B);
+int rvll_dev_upload_theta(rvll_handle* h, const double* theta, int64_t B);
+int rvll_dev_upload_cube(rvll_handle* h, const double* cube, int64_t B);
+/* Fill the resident cube buffer with counter-based uniforms on the device.   */
+int rvll_dev_fill_cube(rvll_handle* h, int64_t B, uint64_t seed);
+/* Launch on the handle's compute stream; asynchronous.                        */
+int rvll_dev_prior(rvll_handle* h, int64_t B);                 /* cube -> theta  */
+int rvll_dev_loglike(rvll_handle* h, int64_t B);               /* theta -> logL  */
+int rvll_dev_download(rvll_handle* h, int64_t B, double* theta /*or NULL*/,
+                      double* logL /*or NULL*/, int32_t* flags /*or NULL*/);
+int rvll_dev_sync(rvll_handle* h);
+/* Time `iters` log-L launches over the resident theta with HIP events on the
+ * compute stream (after `warmup` untimed launches).                          */
+int rvll_dev_time_loglike(rvll_handle* h, int64_t B, int32_t warmup, int32_t iters,
+                          rvll_timing* out);
+
+/* ---- launch geometry ------------------------------------------------------ */
+/* points_per_block <= 0 restores the built-in heuristic.                     */
+int rvll_set_points_per_block(rvll_handle* h, int32_t points_per_block);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI ----------------------- */
+/* 128-byte opaque id created on rank 0 and handed to every rank out of band.  */
+#define RVLL_COMM_ID_BYTES 128
+int rvll_comm_unique_id(unsigned char id[RVLL_COMM_ID_BYTES]);
+int rvll_comm_init(rvll_handle* h, const unsigned char id[RVLL_COMM_ID_BYTES],
+                   int32_t nranks, int32_t rank);
+/* All ranks hold B_local resident log-L values; gathers nranks*B_local values
+ * on the device (rank-major) on the comm stream, ordered after the compute
+ * stream's work.  Asynchronous.                                               */
+int rvll_allgather_logl(rvll_handle* h, int64_t B_local);
+int rvll_download_gathered(rvll_handle* h, int64_t B_total, double* logL_all);
+int rvll_comm_destroy(rvll_handle* h);
+
+/* ---- housekeeping ---------------------------------------------------------- */
+const char* rvll_last_error(void);
+int rvll_version(int32_t* major, int32_t* minor);
+int rvll_device_count(int32_t* count);
+int rvll_device_name(int32_t device, char* buf, int32_t buflen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RVLL_H */

@@ -1,0 +1,5 @@
+"""CPU oracle — TEST INFRASTRUCTURE ONLY (see oracle/rvll_oracle.c header).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+package.  Nothing under evidence_amd/ does.
+"""

@@ -1,0 +1,115 @@
+"""ctypes front end of oracle/librvll_oracle.so (the C restatement of the reference's
+RV log-likelihood) and of oracle/_ref/libtrueanomaly_ref.so (the reference's own
+Kepler solver compiled from /root/reference by `make -C oracle ref`).
+
+TEST INFRASTRUCTURE ONLY — never imported by evidence_amd/.
+"""
+import ctypes as C
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+from evidence_amd import _abi
+from evidence_amd.layout import ModelLayout
+
+HERE = Path(__file__).resolve().parent
+LIB = HERE / "librvll_oracle.so"
+REF_LIB = HERE / "_ref" / "libtrueanomaly_ref.so"
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_lib = None
+_ref = None
+
+
+def build(ref=True):
+    """Compile the oracle (and, when /root/reference exists, the reference solver)."""
+    subprocess.run(["make", "-s", "-C", str(HERE)], check=True)
+    if ref and Path("/root/reference/evidence/rvmodel/trueanomaly.c").exists():
+        subprocess.run(["make", "-s", "-C", str(HERE), "ref"], check=True)
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not LIB.exists():
+            build(ref=False)
+        lib = C.CDLL(str(LIB))
+        lib.rvo_trueanomaly.restype = C.c_int
+        lib.rvo_trueanomaly.argtypes = [_dp, C.c_int, C.c_double, _dp, C.c_int, C.c_double, _ip]
+        lib.rvo_loglike_batch.restype = C.c_int
+        lib.rvo_loglike_batch.argtypes = [C.POINTER(_abi.Layout), _dp, _dp, _dp, _ip, C.c_int, _dp, _dp,
+                                          C.c_long, _dp, _ip, C.c_int]
+        lib.rvo_iteration_counts.restype = C.c_int
+        lib.rvo_iteration_counts.argtypes = [C.POINTER(_abi.Layout), _dp, C.c_int, _dp, _ip]
+        lib.rvo_max_threads.restype = C.c_int
+        _lib = lib
+    return _lib
+
+
+def load_ref():
+    """The reference's own trueanomaly(), or None when oracle/_ref was not built."""
+    global _ref
+    if _ref is None and REF_LIB.exists():
+        lib = C.CDLL(str(REF_LIB))
+        lib.trueanomaly.restype = C.c_int
+        lib.trueanomaly.argtypes = [_dp, C.c_int, C.c_double, _dp, C.c_int, C.c_double]
+        _ref = lib
+    return _ref
+
+
+def trueanomaly(M, ecc, itmax=10000, tol=1e-4, want_iters=False):
+    M = np.ascontiguousarray(M, dtype=np.float64)
+    nu = np.zeros_like(M)
+    iters = np.zeros(M.shape[0], dtype=np.int32)
+    rc = load().rvo_trueanomaly(_abi.as_dp(M), M.shape[0], float(ecc), _abi.as_dp(nu), int(itmax), float(tol),
+                                _abi.as_ip(iters))
+    return (nu, rc, iters) if want_iters else (nu, rc)
+
+
+def ref_trueanomaly(M, ecc, itmax=10000, tol=1e-4):
+    lib = load_ref()
+    if lib is None:
+        raise FileNotFoundError(str(REF_LIB))
+    M = np.ascontiguousarray(M, dtype=np.float64)
+    nu = np.zeros_like(M)
+    rc = lib.trueanomaly(_abi.as_dp(M), M.shape[0], float(ecc), _abi.as_dp(nu), int(itmax), float(tol))
+    return nu, rc
+
+
+class OracleModel:
+    """CPU evaluation of a compiled ModelLayout over an EpochTable."""
+
+    def __init__(self, layout: ModelLayout, table, linpar_series=None):
+        self.layout, self.table = layout, table
+        self._c, self._keep = layout.to_c()
+        self._series = None if linpar_series is None else np.ascontiguousarray(linpar_series, dtype=np.float64)
+        self.lib = load()
+
+    def loglike(self, theta, nthreads=1, return_flags=False):
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        if theta.ndim == 1:
+            theta = theta.reshape(1, -1)
+        assert theta.shape[1] == self.layout.ndim
+        n = theta.shape[0]
+        out = np.empty(n, dtype=np.float64)
+        flags = np.zeros(n, dtype=np.int32)
+        t = self.table
+        rc = self.lib.rvo_loglike_batch(
+            C.byref(self._c), _abi.as_dp(t.time), _abi.as_dp(t.vrad), _abi.as_dp(t.svrad), _abi.as_ip(t.inst_id),
+            t.n_epochs, _abi.as_dp(self._series) if self._series is not None else None,
+            _abi.as_dp(theta), n, _abi.as_dp(out), _abi.as_ip(flags), int(nthreads))
+        if rc != 0:
+            raise MemoryError("oracle allocation failed")
+        return (out, flags) if return_flags else out
+
+    def iteration_counts(self, theta):
+        theta = np.ascontiguousarray(theta, dtype=np.float64).reshape(-1)
+        it = np.zeros((max(1, self.layout.nplanets), self.table.n_epochs), dtype=np.int32)
+        self.lib.rvo_iteration_counts(C.byref(self._c), _abi.as_dp(self.table.time), self.table.n_epochs,
+                                      _abi.as_dp(theta), _abi.as_ip(it))
+        return it[: self.layout.nplanets]
+
+
+def max_threads():
+    return int(load().rvo_max_threads())
