@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py — live-point log-L evaluations per second on N MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`,
+     one rank per GPU; live points shard across ranks, one RCCL all-gather of per-shard log-L per step)
+
+A step = one pass of the hot path over one batch: the fused log-L kernel over B live points
+already resident in HBM (theta uploaded before the timed region), followed — for N > 1 — by
+the all-gather of the per-shard log-L to every rank, on a second HIP stream so that it overlaps
+the next step's kernel.  Weak scaling: B live points PER GPU, fixed as N grows.
+
+Workload: BASELINE.json configs[2] — 3-planet Keplerian, 200 epochs, 2 instruments with
+jitter + offset, 16384 live points (the configuration the >= 1e8 evals/s target is quoted on).
+
+Prints ONE JSON line on rank 0 (see README/DESIGN.md for the field definitions).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+REPO = Path(__file__).resolve().parent
+sys.path.insert(0, str(REPO))
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+from evidence_amd import GpuRVModel  # noqa: E402
+from evidence_amd.synthetic import CONFIGS, make_workload  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VALU_PEAK_TFLOPS = 78.6   # vector fp64 = half of the 157.3 TF fp32 vector rate
+
+WORKLOAD_TEXT = {
+    1: "cfg1: 1-planet circular, 50 epochs, 1 instrument, {b} live points/GPU",
+    2: "cfg2: 1-planet eccentric (e=0.3), 200 epochs, 1 instrument, {b} live points/GPU",
+    3: "cfg3: 3-planet Keplerian, 200 epochs, 2 instruments w/ jitter+offset, {b} live points/GPU",
+    4: "cfg4: 3-planet Keplerian, 1000 epochs, 2 instruments, {b} live points/GPU",
+    5: "cfg5: 5-planet + linear drift, 2000 epochs, 3 instruments, {b} live points/GPU",
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=0, help="live points per GPU (default: the config's)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--points-per-block", type=int, default=0)
+    return ap.parse_args()
+
+
+def algorithmic_bytes_per_launch(ndim, n_epochs, batch):
+    """SURVEY.md §8d, L mode: theta in (8 D) + log-L out (8) per live point, + the epoch table
+    (t, y, sigma^2 f64 + instrument id i32 = 28 B/epoch) once per launch."""
+    return batch * (8 * ndim + 8) + 28 * n_epochs
+
+
+def flops_per_eval(nplanets, n_epochs, mean_iters):
+    """SURVEY.md §8d convention: F_eval = Ne (Np (128 + 96 n_it) + 60)."""
+    return n_epochs * (nplanets * (128.0 + 96.0 * mean_iters) + 60.0)
+
+
+def cpu_baseline(w, layout, theta, gpu_logl, seconds):
+    """The oracle (C restatement of the reference path) on this node's host cores, OpenMP over live
+    points, on a bounded sample of the same workload.  Reported baseline, not the target."""
+    from oracle import oracle as orc            # checker + CPU baseline only
+    om = orc.OracleModel(layout, w.table)
+    threads = min(orc.max_threads(), os.cpu_count() or 1)
+    n = theta.shape[0]
+    ref = om.loglike(theta, nthreads=threads)   # warm + parity sample
+    err = np.abs(gpu_logl - ref) / np.maximum(np.abs(ref), 1e-300)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        om.loglike(theta, nthreads=threads)
+        done += n
+        el = time.perf_counter() - t0
+        if el >= seconds:
+            break
+    t1 = time.perf_counter()
+    om.loglike(theta[: max(1, n // 8)], nthreads=1)
+    one = (max(1, n // 8)) / (time.perf_counter() - t1)
+    iters = np.concatenate([om.iteration_counts(theta[i]).ravel() for i in range(0, n, max(1, n // 64))])
+    return {
+        "value": done / el, "unit": "evals/s", "cores": threads, "kind": "port",
+        "sample": f"{done} evaluations ({done // n} passes over the same {n}-point batch, {el:.1f} s)",
+        "single_thread_evals_per_s": one,
+        "host_cpus": os.cpu_count(),
+    }, float(err.max()), float(iters.mean())
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist      # control plane only: barrier, max-reduce, id exchange
+        dist.init_process_group("gloo")
+
+    w = make_workload(args.config)
+    B = args.batch or (CONFIGS[args.config]["batch"] // (8 if args.config in (4, 5) else 1))
+    theta = w.sample_theta(B, seed=1234 + rank)
+    model = GpuRVModel(w.fixedpardict, w.table, w.parnames, device=local_rank)
+    if args.points_per_block:
+        model.set_points_per_block(args.points_per_block)
+    model.dev_upload_theta(theta)                # inputs resident in HBM before the timed region
+
+    gather = "none"
+    if world > 1:
+        ids = [GpuRVModel.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        model.comm_init(ids[0], world, rank)
+        gather = "rccl"
+
+    def step():
+        model.dev_loglike(B)
+        if world > 1:
+            model.allgather_logl(B)
+
+    for _ in range(args.warmup):
+        step()
+    model.dev_sync()
+    if dist:
+        dist.barrier()
+    model.dev_sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    model.dev_sync()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        dist.barrier()
+        import torch
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    if world > 1:                                # every rank holds all N*B log-L values
+        allv = model.download_gathered(world * B)
+        _, mine, _ = model.dev_download(B)
+        assert np.array_equal(allv[rank * B:(rank + 1) * B], mine), "all-gather slot mismatch"
+
+    if rank == 0:
+        value = world * B * args.steps / elapsed
+        # dominant kernel, measured live with HIP events on the stream it is launched on
+        tm = model.dev_time_loglike(B, warmup=max(3, args.warmup // 4), iters=max(10, min(args.steps, 200)))
+        _, gpu_logl, flags = model.dev_download(B, flags=True)
+        kern_s = tm["kernel_ms_mean"] * 1e-3
+        abytes = algorithmic_bytes_per_launch(w.ndim, w.table.n_epochs, B)
+        achieved = abytes / kern_s / 1e9
+        out = {
+            "metric": "live_point_logL_evals_per_sec", "value": value, "unit": "evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": WORKLOAD_TEXT[args.config].format(b=B), "cfg": args.config,
+                       "live_points_per_gpu": B, "epochs": w.table.n_epochs, "planets": len(model.layout.planets),
+                       "instruments": len(w.table.insts), "free_parameters": w.ndim,
+                       "parallelism": f"live-point shards x{world}", "allgather": gather},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "loglike_kernel", "kernel_ms_mean": tm["kernel_ms_mean"],
+                         "kernel_ms_min": tm["kernel_ms_min"], "algorithmic_bytes_per_launch": abytes,
+                         "points_per_block": tm["points_per_block"], "blocks": tm["blocks"],
+                         "kernel_evals_per_s": B / kern_s,
+                         "note": "fused kernel is fp64-VALU bound, not HBM bound (DESIGN.md); see valu_fp64"},
+        }
+        if not args.no_cpu and world == 1:
+            cpu, perr, mean_it = cpu_baseline(w, model.layout, theta, gpu_logl, args.cpu_seconds)
+            out["cpu_baseline"] = cpu
+            out["parity_max_rel_err_vs_oracle"] = perr
+            f_eval = flops_per_eval(len(model.layout.planets), w.table.n_epochs, mean_it)
+            tf = B / kern_s * f_eval / 1e12
+            out["roofline"]["valu_fp64"] = {"achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                            "frac": tf / FP64_VALU_PEAK_TFLOPS, "flops_per_eval": f_eval,
+                                            "mean_newton_steps": mean_it,
+                                            "kepler_solves_per_s": B / kern_s * len(model.layout.planets) * w.table.n_epochs}
+        print(json.dumps(out), flush=True)
+
+    if world > 1:
+        model.comm_destroy()
+    model.close()
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

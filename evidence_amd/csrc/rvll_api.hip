@@ -126,7 +126,11 @@ struct rvll_handle {
     long long cap = 0;
     double*  d_theta = nullptr;
     double*  d_cube = nullptr;
-    double*  d_logL = nullptr;
+    double*  d_logL2[2] = {nullptr, nullptr};   // ping-pong: an all-gather may still read one
+    int      logl_cur = 0;                      // buffer the next launch writes
+    int      logl_last = 0;                     // buffer the last launch wrote (download source)
+    hipEvent_t ev_gather_done[2] = {nullptr, nullptr};
+    bool     gather_pending[2] = {false, false};
     int32_t* d_flags = nullptr;
 
     // geometry
@@ -250,12 +254,16 @@ int ensure_capacity(rvll_handle* h, long long B)
 {
     if (B <= h->cap) return RVLL_OK;
     long long cap = std::max<long long>(B, 1024);
-    dev_free(h->d_theta); dev_free(h->d_cube); dev_free(h->d_logL); dev_free(h->d_flags);
+    if (h->comm) HIP_TRY(hipStreamSynchronize(h->comm));
+    if (h->compute) HIP_TRY(hipStreamSynchronize(h->compute));
+    dev_free(h->d_theta); dev_free(h->d_cube); dev_free(h->d_logL2[0]); dev_free(h->d_logL2[1]); dev_free(h->d_flags);
+    h->gather_pending[0] = h->gather_pending[1] = false;
     h->cap = 0;
     const size_t D = (size_t)std::max(1, h->L.ndim);
     HIP_TRY(hipMalloc(&h->d_theta, sizeof(double) * D * (size_t)cap));
     HIP_TRY(hipMalloc(&h->d_cube,  sizeof(double) * D * (size_t)cap));
-    HIP_TRY(hipMalloc(&h->d_logL,  sizeof(double) * (size_t)cap));
+    HIP_TRY(hipMalloc(&h->d_logL2[0], sizeof(double) * (size_t)cap));
+    HIP_TRY(hipMalloc(&h->d_logL2[1], sizeof(double) * (size_t)cap));
     HIP_TRY(hipMalloc(&h->d_flags, sizeof(int32_t) * (size_t)cap));
     h->cap = cap;
     return RVLL_OK;
@@ -356,6 +364,8 @@ int rvll_create(const rvll_layout* layout, const double* time, const double* vra
     CREATE_TRY(hipStreamCreateWithFlags(&h->compute, hipStreamNonBlocking));
     CREATE_TRY(hipStreamCreateWithFlags(&h->comm, hipStreamNonBlocking));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_compute_done, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&h->ev_gather_done[0], hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&h->ev_gather_done[1], hipEventDisableTiming));
 
     const size_t nb = sizeof(double) * (size_t)n_epochs;
     std::vector<double> s2((size_t)n_epochs);
@@ -393,8 +403,9 @@ int rvll_destroy(rvll_handle* h)
     if (h->compute) (void)hipStreamSynchronize(h->compute);
     if (h->comm) (void)hipStreamSynchronize(h->comm);
     free_priors(h);
-    dev_free(h->d_theta); dev_free(h->d_cube); dev_free(h->d_logL); dev_free(h->d_flags);
+    dev_free(h->d_theta); dev_free(h->d_cube); dev_free(h->d_logL2[0]); dev_free(h->d_logL2[1]); dev_free(h->d_flags);
     dev_free(h->d_gather);
+    for (auto& e : h->ev_gather_done) if (e) (void)hipEventDestroy(e);
     dev_free(h->d_t); dev_free(h->d_y); dev_free(h->d_s2); dev_free(h->d_inst); dev_free(h->d_linpar);
     dev_free(h->d_planets); dev_free(h->d_insts); dev_free(h->d_linslots);
     if (h->ev_compute_done) (void)hipEventDestroy(h->ev_compute_done);
@@ -515,10 +526,16 @@ int rvll_dev_loglike(rvll_handle* h, int64_t B)
     if (rc) return rc;
     if (B < 0 || B > h->cap) return fail(RVLL_E_INVALID, "B %lld outside reserved capacity %lld", (long long)B, h->cap);
     if (B == 0) return RVLL_OK;
+    const int buf = h->logl_cur;
+    if (h->gather_pending[buf]) {             // an all-gather may still be reading this buffer
+        HIP_TRY(hipStreamWaitEvent(h->compute, h->ev_gather_done[buf], 0));
+        h->gather_pending[buf] = false;
+    }
     rvll::LoglikeArgs a;
-    rc = build_args(h, h->d_theta, h->d_logL, h->d_flags, B, &a);
+    rc = build_args(h, h->d_theta, h->d_logL2[buf], h->d_flags, B, &a);
     if (rc) return rc;
     HIP_TRY(rvll::launch_loglike(a, h->compute));
+    h->logl_last = buf;
     return RVLL_OK;
 }
 
@@ -529,7 +546,7 @@ int rvll_dev_download(rvll_handle* h, int64_t B, double* theta, double* logL, in
     if (B < 0 || B > h->cap) return fail(RVLL_E_INVALID, "B %lld outside reserved capacity %lld", (long long)B, h->cap);
     if (B > 0) {
         if (theta) HIP_TRY(hipMemcpyAsync(theta, h->d_theta, sizeof(double) * (size_t)B * (size_t)h->L.ndim, hipMemcpyDeviceToHost, h->compute));
-        if (logL)  HIP_TRY(hipMemcpyAsync(logL, h->d_logL, sizeof(double) * (size_t)B, hipMemcpyDeviceToHost, h->compute));
+        if (logL)  HIP_TRY(hipMemcpyAsync(logL, h->d_logL2[h->logl_last], sizeof(double) * (size_t)B, hipMemcpyDeviceToHost, h->compute));
         if (flags) HIP_TRY(hipMemcpyAsync(flags, h->d_flags, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, h->compute));
     }
     HIP_TRY(hipStreamSynchronize(h->compute));
@@ -552,8 +569,9 @@ int rvll_dev_time_loglike(rvll_handle* h, int64_t B, int32_t warmup, int32_t ite
     if (!out || iters < 1 || warmup < 0) return fail(RVLL_E_INVALID, "bad timing arguments");
     if (B < 1 || B > h->cap) return fail(RVLL_E_INVALID, "B %lld outside reserved capacity %lld", (long long)B, h->cap);
     rvll::LoglikeArgs a;
-    rc = build_args(h, h->d_theta, h->d_logL, h->d_flags, B, &a);
+    rc = build_args(h, h->d_theta, h->d_logL2[h->logl_cur], h->d_flags, B, &a);
     if (rc) return rc;
+    h->logl_last = h->logl_cur;
     for (int i = 0; i < warmup; ++i) HIP_TRY(rvll::launch_loglike(a, h->compute));
     std::vector<hipEvent_t> ev((size_t)iters + 1, nullptr);
     int status = RVLL_OK;
@@ -682,7 +700,11 @@ int rvll_allgather_logl(rvll_handle* h, int64_t B_local)
     // comm stream waits for the log-L kernel; the next batch's kernel may start meanwhile
     HIP_TRY(hipEventRecord(h->ev_compute_done, h->compute));
     HIP_TRY(hipStreamWaitEvent(h->comm, h->ev_compute_done, 0));
-    RCCL_TRY(g_rccl.AllGather(h->d_logL, h->d_gather, (size_t)B_local, kNcclFloat64, h->nccl_comm, h->comm));
+    const int buf = h->logl_last;             // what the last launch wrote
+    RCCL_TRY(g_rccl.AllGather(h->d_logL2[buf], h->d_gather, (size_t)B_local, kNcclFloat64, h->nccl_comm, h->comm));
+    HIP_TRY(hipEventRecord(h->ev_gather_done[buf], h->comm));
+    h->gather_pending[buf] = true;
+    h->logl_cur = buf ^ 1;                    // the next launch writes the other buffer
     return RVLL_OK;
 }
 

@@ -27,11 +27,14 @@ class GpuRVModel:
     linpar_dict   optional {key: series[Ne]} for `linpar_{key}` terms (rvmodel:131-136,210-212)
     priordict     optional {parname: PriorSpec}; enables prior_transform*
     device        HIP device index (default: current device)
+    tol, itmax    Newton stop rule of the Kepler solver; defaults 1e-4 and 10000 are what the
+                  reference passes (rvmodel/__init__.py:466,491) — change them and parity is gone
     """
 
     def __init__(self, fixedpardict: Dict[str, float], datadict, parnames: Sequence[str],
                  linpar_dict: Optional[Dict[str, np.ndarray]] = None,
-                 priordict: Optional[Dict[str, PriorSpec]] = None, device: int = -1):
+                 priordict: Optional[Dict[str, PriorSpec]] = None, device: int = -1,
+                 tol: Optional[float] = None, itmax: Optional[int] = None):
         self._lib = _abi.load()          # raises RvllLibraryError when the HIP library is absent
         self._h = _abi.Handle()
         self.fixedpardict = dict(fixedpardict)
@@ -40,6 +43,10 @@ class GpuRVModel:
         self.insts = list(self.table.insts)
         self.linpar_dict = dict(linpar_dict) if linpar_dict else {}
         self.layout = compile_layout(parnames, self.fixedpardict, self.insts, list(self.linpar_dict))
+        if tol is not None:
+            self.layout.tol = float(tol)
+        if itmax is not None:
+            self.layout.itmax = int(itmax)
         self.parnames = list(self.layout.parnames)
         self.nplanets = self.layout.nplanets
         self.drift_in_model = self.layout.has_drift
