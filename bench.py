@@ -67,12 +67,27 @@ def flops_per_eval(nplanets, n_epochs, mean_iters):
     return n_epochs * (nplanets * (128.0 + 96.0 * mean_iters) + 60.0)
 
 
+def host_cpu_share():
+    """CPU cores this process may actually use: the cgroup quota (the GPU box gives 16 of its 256
+    logical CPUs to a one-GPU job), else the affinity mask; RVLL_CPU_THREADS overrides."""
+    if os.environ.get("RVLL_CPU_THREADS"):
+        return max(1, int(os.environ["RVLL_CPU_THREADS"]))
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(w, layout, theta, gpu_logl, seconds):
     """The oracle (C restatement of the reference path) on this node's host cores, OpenMP over live
     points, on a bounded sample of the same workload.  Reported baseline, not the target."""
     from oracle import oracle as orc            # checker + CPU baseline only
     om = orc.OracleModel(layout, w.table)
-    threads = min(orc.max_threads(), os.cpu_count() or 1)
+    threads = host_cpu_share()
     n = theta.shape[0]
     ref = om.loglike(theta, nthreads=threads)   # warm + parity sample
     err = np.abs(gpu_logl - ref) / np.maximum(np.abs(ref), 1e-300)
@@ -91,7 +106,7 @@ def cpu_baseline(w, layout, theta, gpu_logl, seconds):
         "value": done / el, "unit": "evals/s", "cores": threads, "kind": "port",
         "sample": f"{done} evaluations ({done // n} passes over the same {n}-point batch, {el:.1f} s)",
         "single_thread_evals_per_s": one,
-        "host_cpus": os.cpu_count(),
+        "host_logical_cpus": os.cpu_count(),
     }, float(err.max()), float(iters.mean())
 
 

@@ -135,6 +135,8 @@ struct rvll_handle {
 
     // geometry
     int pb_override = 0;
+    long long geo_B = -1;     // batch size the cached geometry was chosen for
+    int geo_pb = 1;
     int chunk_items = 4096;
     int n_cu = 256;
 
@@ -191,31 +193,47 @@ int validate_layout(const rvll_layout* L)
     return RVLL_OK;
 }
 
-// Launch geometry: how many live points one 256-thread workgroup takes.  Lane
-// efficiency (flattened items per 256-wide round) x how evenly the grid fills the
-// CUs at the occupancy the kernel reaches.
-int choose_points_per_block(const rvll_handle* h, long long B)
+// Launch geometry: how many live points one 256-thread workgroup takes.
+//
+// A workgroup puts one wave on each SIMD of its CU and walks ceil(PB*Ne/256) rounds of
+// flattened (point, epoch) items; workgroups are dealt round-robin over the CUs.  The
+// fp64 pipes are issue-bound, so a CU's time ~ (workgroups it receives) x (rounds each),
+// mildly worse when fewer than ~3 waves per SIMD are resident to hide latency.  Pick the
+// PB that minimises that, subject to the LDS carve fitting.
+size_t lds_bytes_for(const rvll_handle* h, int pb)
+{
+    rvll::LoglikeArgs a{};
+    a.PB = pb; a.D = h->L.ndim; a.Np = h->L.nplanets; a.Ni = h->L.ninst; a.nlin = h->L.nlinpar;
+    a.CH = std::min(h->chunk_items, std::max(rvll::kThreads, pb * h->Ne));
+    a.CH = (a.CH + 1) & ~1;
+    return rvll::loglike_lds_bytes(a);
+}
+
+int choose_points_per_block(rvll_handle* h, long long B)
 {
     if (h->pb_override > 0) return std::min(h->pb_override, rvll::kMaxPointsPerBlock);
+    if (h->geo_B == B) return h->geo_pb;
     const int Ne = h->Ne;
     const int T = rvll::kThreads;
-    const int blocks_per_cu = 4;
-    const double slots = (double)h->n_cu * blocks_per_cu;
     int best = 1;
-    double best_score = -1.;
+    double best_cost = 1e300;
     for (int pb = 1; pb <= rvll::kMaxPointsPerBlock; ++pb) {
         if ((long long)pb > std::max(1LL, B)) break;
+        const size_t lds = lds_bytes_for(h, pb);
+        if (pb > 1 && lds > 60 * 1024) break;
         const long long items = (long long)pb * Ne;
-        if (pb > 1 && items > h->chunk_items) break;
-        const long long rounds = (items + T - 1) / T;
-        const double lane_eff = (double)items / (double)(rounds * T);
+        const double rounds = (double)((items + T - 1) / T);
         const double blocks = std::ceil((double)B / pb);
-        const double waves_of_blocks = std::ceil(blocks / slots);
-        const double fill = blocks / (waves_of_blocks * slots);
-        // many small grids only half-fill the chip; weigh that softly (occupancy still hides latency)
-        const double score = lane_eff * (0.5 + 0.5 * fill);
-        if (score > best_score + 1e-9) { best_score = score; best = pb; }
+        const double per_cu = std::ceil(blocks / h->n_cu);
+        const int occ = rvll::loglike_blocks_per_cu(lds);
+        const double resident = std::min(per_cu, (double)occ);
+        const double latency_penalty = resident >= 4 ? 1.0 : resident >= 3 ? 1.03 : resident >= 2 ? 1.10 : 1.5;
+        // workgroups beyond the resident set run in further rounds of `occ` per CU
+        const double cost = per_cu * rounds * latency_penalty;
+        if (cost < best_cost * (1.0 - 1e-9)) { best_cost = cost; best = pb; }
     }
+    h->geo_B = B;
+    h->geo_pb = best;
     return best;
 }
 

@@ -44,6 +44,8 @@ struct LoglikeArgs {
 
 size_t loglike_lds_bytes(const LoglikeArgs& a);
 hipError_t launch_loglike(const LoglikeArgs& a, hipStream_t stream);
+// resident 256-thread workgroups per CU for a given dynamic-LDS size (occupancy query)
+int loglike_blocks_per_cu(size_t lds_bytes);
 
 struct PriorArgs {
     const double* cube;      // [B, D]

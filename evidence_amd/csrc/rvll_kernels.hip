@@ -149,7 +149,8 @@ __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx&
     return 0.5 * log(var) + res * res / (2 * var);                          // rvmodel:80
 }
 
-__global__ __launch_bounds__(kThreads)
+// 4 workgroups of 256 per CU (4 waves/SIMD): caps the kernel at 128 VGPRs
+__global__ __launch_bounds__(kThreads, 4)
 void loglike_kernel(const LoglikeArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -455,6 +456,14 @@ void fill_cube_kernel(double* cube, long long n, uint64_t seed)
 size_t loglike_lds_bytes(const LoglikeArgs& a)
 {
     return (size_t)carve(a.PB, a.D, a.Np, a.Ni, a.nlin, a.CH).total_doubles * sizeof(double);
+}
+
+int loglike_blocks_per_cu(size_t lds_bytes)
+{
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, loglike_kernel, kThreads, lds_bytes) != hipSuccess || n < 1)
+        n = 1;
+    return n > 8 ? 8 : n;
 }
 
 hipError_t launch_loglike(const LoglikeArgs& a, hipStream_t stream)
