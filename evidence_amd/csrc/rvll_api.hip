@@ -672,6 +672,28 @@ int rvll_prior_loglike_batch(rvll_handle* h, const double* cube, int64_t B,
     return rvll_dev_download(h, B, theta_out, logL, flags);
 }
 
+// ---- diagnostics ---------------------------------------------------------------------
+int rvll_debug_eval(rvll_handle* h, int32_t op, const double* x, const double* y, int64_t n, double* out)
+{
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!x || !out || n < 1) return fail(RVLL_E_INVALID, "bad debug_eval arguments");
+    double *dx = nullptr, *dy = nullptr, *dout = nullptr;
+    const size_t nb = sizeof(double) * (size_t)n;
+    int status = RVLL_OK;
+    hipError_t e = hipMalloc(&dx, nb);
+    if (e == hipSuccess) e = hipMalloc(&dout, nb);
+    if (e == hipSuccess && y) e = hipMalloc(&dy, nb);
+    if (e == hipSuccess) e = hipMemcpy(dx, x, nb, hipMemcpyHostToDevice);
+    if (e == hipSuccess && y) e = hipMemcpy(dy, y, nb, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = rvll::launch_debug_eval(op, dx, dy, (long long)n, dout, h->compute);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->compute);
+    if (e == hipSuccess) e = hipMemcpy(out, dout, nb, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) status = fail(RVLL_E_HIP, "debug_eval: %s", hipGetErrorString(e));
+    dev_free(dx); dev_free(dy); dev_free(dout);
+    return status;
+}
+
 // ---- multi-GPU ---------------------------------------------------------------------
 int rvll_comm_unique_id(unsigned char id[RVLL_COMM_ID_BYTES])
 {

@@ -56,6 +56,7 @@ struct PriorArgs {
 };
 hipError_t launch_prior(const PriorArgs& a, hipStream_t stream);
 
+hipError_t launch_debug_eval(int op, const double* x, const double* y, long long n, double* out, hipStream_t stream);
 hipError_t launch_fill_cube(double* cube, long long n, uint64_t seed, hipStream_t stream);
 
 }  // namespace rvll

@@ -109,7 +109,7 @@ __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx&
                     sincos_f64(E, s, c);
                     const double f  = E - ec * s - M;
                     const double fp = 1 - ec * c;
-                    const double En = E - f / fp;
+                    const double En = E - div_exact(f, fp);            // == f / fp, correctly rounded
                     dE = En - E;
                     E = En;
                     ++steps;
@@ -128,7 +128,7 @@ __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx&
                     // sin nu = sqrt(1-e^2) sin E/(1 - e cos E)  == trueanomaly.c:36 + rvmodel:463
                     const double den = __builtin_fma(-ec, c, 1.0);
                     const double num = __builtin_fma(p45.x, c - ec, -(p45.y * s));
-                    rv = num / den + C0;
+                    rv = div_fast(num, den) + C0;
                 }
             }
             ksum += rv;                                                     // rvmodel:383
@@ -138,7 +138,7 @@ __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx&
 
     if (a.has_drift) {                                                      // rvmodel:242-271
         const double* d = cx.dr + pl * 6;
-        const double tt = (t - d[4]) / 365.25;
+        const double tt = (t - d[4]) * (1.0 / 365.25);
         const double t2 = tt * tt;
         rvm += d[0] * tt + d[1] * t2 + d[2] * (t2 * tt) + d[3] * (t2 * t2);
     }
@@ -146,7 +146,7 @@ __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx&
         rvm += cx.lin[pl * a.nlin + k] * a.linpar[(size_t)k * a.Ne + j];
 
     const double res = y - rvm;                                             // rvmodel:215
-    return 0.5 * log(var) + res * res / (2 * var);                          // rvmodel:80
+    return 0.5 * log_pos(var) + div_fast(res * res, 2 * var);               // rvmodel:80
 }
 
 // 4 workgroups of 256 per CU (4 waves/SIMD): caps the kernel at 128 VGPRs
@@ -451,7 +451,41 @@ void fill_cube_kernel(double* cube, long long n, uint64_t seed)
         cube[i] = uniform01(seed, (uint64_t)i);
 }
 
+// device-math self test (rvll_debug_eval): out[i] = op(x[i], y[i])
+__global__ __launch_bounds__(kThreads)
+void debug_eval_kernel(int op, const double* x, const double* y, long long n, double* out)
+{
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads) {
+        const double a = x[i];
+        const double b = y ? y[i] : 0.;
+        double s, c, r;
+        switch (op) {
+        case 0: sincos_f64(a, s, c); r = s; break;
+        case 1: sincos_f64(a, s, c); r = c; break;
+        case 2: r = div_exact(a, b); break;
+        case 3: r = a / b; break;
+        case 4: r = div_fast(a, b); break;
+        case 5: r = log_pos(a); break;
+        case 6: r = log(a); break;
+        case 7: r = ndtri_f64(a); break;
+        case 8: sincos_f64(a, s, c); rotate_small(b, s, c); r = s; break;
+        case 9: sincos_f64(a, s, c); rotate_small(b, s, c); r = c; break;
+        default: r = NAN; break;
+        }
+        out[i] = r;
+    }
+}
+
 }  // namespace
+
+hipError_t launch_debug_eval(int op, const double* x, const double* y, long long n, double* out, hipStream_t stream)
+{
+    if (n <= 0) return hipSuccess;
+    long long blocks = (n + kThreads - 1) / kThreads;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(debug_eval_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, op, x, y, n, out);
+    return hipGetLastError();
+}
 
 size_t loglike_lds_bytes(const LoglikeArgs& a)
 {

@@ -23,6 +23,58 @@ namespace rvll {
 RVLL_HD double as_double(uint64_t u) { return __builtin_bit_cast(double, u); }
 RVLL_HD uint64_t as_u64(double d) { return __builtin_bit_cast(uint64_t, d); }
 
+// Both minimax kernels on r in [-pi/4, pi/4] (sin: degree 13 odd, cos: degree 14 even).
+// On the device the two Horner chains are written as ONE block of interleaved
+// v_fma_f64: hipcc otherwise lowers each step to v_mov_b64 (coefficient copy) + v_fmac_f64,
+// which costs a third of the sin/cos time on an issue-bound fp64 pipe, and it pads
+// separate asm statements with s_nop.  Pure VALU: no memory operations, no hazards.
+RVLL_HD void sincos_kernel(double r, double& sr, double& cr)
+{
+    constexpr double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+                     S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+                     S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    constexpr double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+                     C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+                     C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+#if defined(__HIP_DEVICE_COMPILE__)
+    double z, t;
+    asm("v_mul_f64 %2, %4, %4\n\t"
+        "v_fma_f64 %0, %2, %10, %9\n\t"
+        "v_fma_f64 %1, %2, %16, %15\n\t"
+        "v_fma_f64 %0, %2, %0, %8\n\t"
+        "v_fma_f64 %1, %2, %1, %14\n\t"
+        "v_fma_f64 %0, %2, %0, %7\n\t"
+        "v_fma_f64 %1, %2, %1, %13\n\t"
+        "v_fma_f64 %0, %2, %0, %6\n\t"
+        "v_fma_f64 %1, %2, %1, %12\n\t"
+        "v_fma_f64 %0, %2, %0, %5\n\t"
+        "v_fma_f64 %1, %2, %1, %11\n\t"
+        "v_mul_f64 %3, %4, %2\n\t"
+        "v_fma_f64 %1, %2, %1, -0.5\n\t"
+        "v_fma_f64 %0, %3, %0, %4\n\t"
+        "v_fma_f64 %1, %2, %1, 1.0"
+        : "=&v"(sr), "=&v"(cr), "=&v"(z), "=&v"(t)
+        : "v"(r), "v"(S1), "v"(S2), "v"(S3), "v"(S4), "v"(S5), "v"(S6),
+          "v"(C1), "v"(C2), "v"(C3), "v"(C4), "v"(C5), "v"(C6));
+#else
+    const double z = r * r;
+    double ps = __builtin_fma(z, S6, S5);
+    double pc = __builtin_fma(z, C6, C5);
+    ps = __builtin_fma(z, ps, S4);
+    pc = __builtin_fma(z, pc, C4);
+    ps = __builtin_fma(z, ps, S3);
+    pc = __builtin_fma(z, pc, C3);
+    ps = __builtin_fma(z, ps, S2);
+    pc = __builtin_fma(z, pc, C2);
+    ps = __builtin_fma(z, ps, S1);
+    pc = __builtin_fma(z, pc, C1);
+    const double t = r * z;
+    pc = __builtin_fma(z, pc, -0.5);
+    sr = __builtin_fma(t, ps, r);
+    cr = __builtin_fma(z, pc, 1.0);
+#endif
+}
+
 // sin and cos of x, one shared range reduction.
 RVLL_HD void sincos_f64(double x, double& s_out, double& c_out)
 {
@@ -33,40 +85,94 @@ RVLL_HD void sincos_f64(double x, double& s_out, double& c_out)
 
     // k = nearest integer to x*2/pi, via the round-to-nearest-even of the add;
     // its low bits sit in the low mantissa word of t.
-    const double t  = x * TWO_OVER_PI + MAGIC;
+    const double t  = __builtin_fma(x, TWO_OVER_PI, MAGIC);
     const double fk = t - MAGIC;
     const uint32_t q = (uint32_t)as_u64(t);
 
     // r1 = x - k*PIO2_HI is exact (|r1| < 1, multiple of 2^-53); second word rounds once.
     const double r1 = __builtin_fma(-fk, PIO2_HI, x);
     const double r  = __builtin_fma(-fk, PIO2_LO, r1);
-    const double z  = r * r;
-
-    // sin(r) on [-pi/4, pi/4]
-    double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
-    ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
-    ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
-    ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
-    ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
-    const double sr = __builtin_fma(r * z, ps, r);
-
-    // cos(r) on [-pi/4, pi/4]
-    double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
-    pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
-    pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
-    pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
-    pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
-    pc = __builtin_fma(z, pc, -0.5);
-    const double cr = __builtin_fma(z, pc, 1.0);
+    double sr, cr;
+    sincos_kernel(r, sr, cr);
 
     // quadrant: q&1 swaps, bit 1 of q flips sin, bit 1 of (q+1) flips cos
     const bool swap = (q & 1u) != 0u;
-    double s = swap ? cr : sr;
-    double c = swap ? sr : cr;
+    const double s = swap ? cr : sr;
+    const double c = swap ? sr : cr;
     const uint64_t ssign = (uint64_t)(q & 2u) << 62;
     const uint64_t csign = (uint64_t)((q + 1u) & 2u) << 62;
     s_out = as_double(as_u64(s) ^ ssign);
     c_out = as_double(as_u64(c) ^ csign);
+}
+
+// n / d by reciprocal refinement.  div_exact is the sequence hipcc itself emits for an
+// IEEE fp64 division (v_rcp_f64, two Newton steps, quotient, one residual correction) minus
+// v_div_scale / v_div_fmas / v_div_fixup, which only act when an exponent is near the ends
+// of the range: for finite, normal operands with a normal quotient it returns the correctly
+// rounded quotient, bit for bit what `n / d` gives (tests/test_gpu_math.py).  div_fast drops
+// the residual step (<= ~2 ulp), for quotients that do not feed the Newton stop rule.
+RVLL_HD double recip_refined(double d)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    double y = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-d, y, 1.0);
+    return __builtin_fma(y, e, y);
+#else
+    return 1.0 / d;
+#endif
+}
+RVLL_HD double div_exact(double n, double d)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double y = recip_refined(d);
+    const double q = n * y;
+    const double r = __builtin_fma(-d, q, n);
+    return __builtin_fma(r, y, q);
+#else
+    return n / d;
+#endif
+}
+RVLL_HD double div_fast(double n, double d)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return n * recip_refined(d);
+#else
+    return n / d;
+#endif
+}
+
+// Natural log of a finite positive double: argument split by v_frexp, f = m - 1 with
+// m in [sqrt(1/2), sqrt(2)), s = f/(2+f), and the degree-14 even minimax in s (coefficients:
+// Sun fdlibm e_log.c, public domain).  ~1 ulp; a third of the cost of the library log.
+RVLL_HD double log_pos(double v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (!(v > 0.0 && v < __builtin_inf())) return log(v);          // zero, negative, inf, nan: library path
+    double m = __builtin_amdgcn_frexp_mant(v);                    // [0.5, 1)
+    int    k = __builtin_amdgcn_frexp_exp(v);
+    const bool lowhalf = m < 7.07106781186547524401e-01;
+    m = lowhalf ? m + m : m;
+    k = lowhalf ? k - 1 : k;
+    const double f = m - 1.0;
+    const double s = div_fast(f, 2.0 + f);
+    const double z = s * s;
+    double R = __builtin_fma(z, 1.479819860511658591e-01, 1.531383769920937332e-01);
+    R = __builtin_fma(z, R, 1.818357216161805012e-01);
+    R = __builtin_fma(z, R, 2.222219843214978396e-01);
+    R = __builtin_fma(z, R, 2.857142874366239149e-01);
+    R = __builtin_fma(z, R, 3.999999999940941908e-01);
+    R = __builtin_fma(z, R, 6.666666666666735130e-01);
+    R = R * z;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)k;
+    // k ln2_hi - ((hfsq - (s (hfsq + R) + k ln2_lo)) - f)
+    const double inner = __builtin_fma(s, hfsq + R, dk * 1.90821492927058770002e-10);
+    return __builtin_fma(dk, 6.93147180369123816490e-01, -((hfsq - inner) - f));
+#else
+    return __builtin_log(v);
+#endif
 }
 
 // Rotate (s, c) = (sin E0, cos E0) to E0 + h for a small step |h| <= ~1e-3:

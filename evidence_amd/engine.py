@@ -192,6 +192,15 @@ class GpuRVModel:
     def set_points_per_block(self, pb):
         _abi.check(self._lib.rvll_set_points_per_block(self._h, int(pb)))
 
+    def debug_eval(self, op, x, y=None):
+        """Evaluate one device math routine elementwise (include/rvll.h, diagnostics)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        yy = None if y is None else np.ascontiguousarray(np.broadcast_to(y, x.shape), dtype=np.float64)
+        out = np.empty_like(x)
+        _abi.check(self._lib.rvll_debug_eval(self._h, int(op), _abi.as_dp(x), _abi.as_dp(yy) if yy is not None else None,
+                                             x.size, _abi.as_dp(out)))
+        return out
+
     # ---- multi-GPU ----------------------------------------------------------------------------------
     @staticmethod
     def comm_unique_id():

@@ -235,6 +235,13 @@ int rvll_allgather_logl(rvll_handle* h, int64_t B_local);
 int rvll_download_gathered(rvll_handle* h, int64_t B_total, double* logL_all);
 int rvll_comm_destroy(rvll_handle* h);
 
+/* ---- diagnostics -------------------------------------------------------------- */
+/* Evaluate one device math routine elementwise (tests only; no reference counterpart):
+ * op 0 sin, 1 cos (rvll sincos), 2 div_exact(x,y), 3 x/y (IEEE), 4 div_fast(x,y),
+ * 5 log_pos(x), 6 library log(x), 7 ndtri(x), 8/9 sin/cos after rotate_small by y.  */
+int rvll_debug_eval(rvll_handle* h, int32_t op, const double* x, const double* y,
+                    int64_t n, double* out);
+
 /* ---- housekeeping ---------------------------------------------------------- */
 const char* rvll_last_error(void);
 int rvll_version(int32_t* major, int32_t* minor);

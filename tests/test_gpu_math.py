@@ -1,0 +1,89 @@
+"""GPU: the device math the kernels are built from, checked in isolation through rvll_debug_eval."""
+import numpy as np
+import pytest
+
+from evidence_amd import GpuRVModel
+from evidence_amd.synthetic import make_workload
+
+pytestmark = pytest.mark.gpu
+ULP1 = 2.0 ** -53      # half-ulp of values in [1, 2) == one ulp of values in [0.5, 1)
+
+
+@pytest.fixture(scope="module")
+def dev(gpu_required):
+    w = make_workload(1)
+    m = GpuRVModel(w.fixedpardict, w.table, w.parnames)
+    yield m
+    m.close()
+
+
+def test_div_exact_is_bit_identical_to_ieee_division(dev):
+    """The Newton step E - f/f' must round exactly like the reference's division (trueanomaly.c:29)."""
+    rng = np.random.default_rng(0)
+    n = 4_000_000
+    num = rng.normal(0, 1, n) * 10.0 ** rng.integers(-8, 3, n)       # f = E - e sin E - M
+    den = rng.uniform(0.01, 1.99, n)                                 # 1 - e cos E with e <= 0.99
+    mine = dev.debug_eval(2, num, den)
+    ieee = dev.debug_eval(3, num, den)
+    assert np.array_equal(mine, ieee)
+    assert np.array_equal(ieee, num / den)                           # and both equal the host's correctly rounded quotient
+
+
+def test_div_fast_within_2ulp(dev):
+    rng = np.random.default_rng(1)
+    num = rng.normal(0, 50, 1_000_000)
+    den = rng.uniform(0.01, 3000.0, 1_000_000)
+    got = dev.debug_eval(4, num, den)
+    ref = num / den
+    assert np.max(np.abs(got - ref) / np.abs(ref)) <= 2.5 * 2.0 ** -52
+
+
+def test_sincos_accuracy_over_the_unreduced_mean_anomaly_range(dev):
+    """|M| reaches ~1e4 rad on this path (never range-reduced, rvmodel:459)."""
+    rng = np.random.default_rng(2)
+    x = np.concatenate([rng.uniform(-2.0e4, 2.0e4, 2_000_000), rng.uniform(-7, 7, 500_000),
+                        np.round(rng.uniform(-2.0e4, 2.0e4, 200_000) / (np.pi / 2)) * (np.pi / 2)])
+    xl = x.astype(np.longdouble)
+    s, c = dev.debug_eval(0, x), dev.debug_eval(1, x)
+    es = np.max(np.abs(s.astype(np.longdouble) - np.sin(xl)))
+    ec = np.max(np.abs(c.astype(np.longdouble) - np.cos(xl)))
+    assert es <= 1.5 * ULP1 and ec <= 1.5 * ULP1, (float(es / ULP1), float(ec / ULP1))
+
+
+def test_rotate_small_matches_direct(dev):
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-10, 10, 500_000)
+    h = rng.uniform(-1e-3, 1e-3, 500_000)
+    xl, hl = x.astype(np.longdouble), h.astype(np.longdouble)
+    s, c = dev.debug_eval(8, x, h), dev.debug_eval(9, x, h)
+    ref_s = np.sin(xl) * np.cos(hl) + np.cos(xl) * np.sin(hl)
+    ref_c = np.cos(xl) * np.cos(hl) - np.sin(xl) * np.sin(hl)
+    assert np.max(np.abs(s.astype(np.longdouble) - ref_s)) <= 2.5 * ULP1
+    assert np.max(np.abs(c.astype(np.longdouble) - ref_c)) <= 2.5 * ULP1
+
+
+def test_log_pos_accuracy(dev):
+    rng = np.random.default_rng(4)
+    v = np.concatenate([10.0 ** rng.uniform(-6, 8, 1_000_000), rng.uniform(0.25, 2500.0, 1_000_000),
+                        [1.0, 0.5, 2.0, 0.7071067811865476, 1.4142135623730951, 5e-324, 1e-310, 1e308]])
+    got = dev.debug_eval(5, v)
+    ref = np.log(v.astype(np.longdouble))
+    err = np.abs(got.astype(np.longdouble) - ref) / np.maximum(np.abs(ref), np.longdouble(1e-300))
+    absr = np.abs(got.astype(np.longdouble) - ref)
+    assert np.max(np.minimum(err, absr)) <= 2.5 * 2.0 ** -52
+    special = dev.debug_eval(5, np.array([0.0, -1.0, np.inf, np.nan]))
+    assert special[0] == -np.inf and np.isnan(special[1]) and special[2] == np.inf and np.isnan(special[3])
+
+
+def test_ndtri_against_scipy(dev):
+    from scipy.special import ndtri
+    rng = np.random.default_rng(5)
+    p = np.concatenate([rng.random(500_000), 10.0 ** rng.uniform(-300, -1, 100_000), 1 - 10.0 ** rng.uniform(-15, -1, 100_000),
+                        [0.0, 1.0, 0.5, 0.075, 0.925]])
+    got = dev.debug_eval(7, p)
+    ref = ndtri(p)
+    fin = np.isfinite(ref)
+    assert np.array_equal(got[~fin], ref[~fin])
+    err = np.abs(got[fin] - ref[fin]) / np.maximum(np.abs(ref[fin]), 1e-300)
+    err = np.where(ref[fin] == 0, np.abs(got[fin]), err)
+    assert err.max() <= 1e-13, float(err.max())
