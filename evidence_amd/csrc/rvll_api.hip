@@ -454,7 +454,8 @@ int rvll_set_priors(rvll_handle* h, const rvll_prior* priors, int32_t ndim)
         switch (p.kind) {
         case RVLL_PRIOR_UNIFORM: case RVLL_PRIOR_JEFFREYS: case RVLL_PRIOR_MODJEFFREYS:
         case RVLL_PRIOR_UNIFORMFREQUENCY: case RVLL_PRIOR_NORMAL: case RVLL_PRIOR_LOGNORMAL:
-        case RVLL_PRIOR_TRUNCRAYLEIGH:
+        case RVLL_PRIOR_TRUNCRAYLEIGH: case RVLL_PRIOR_BETA: case RVLL_PRIOR_GAMMA: case RVLL_PRIOR_ALPHA:
+        case RVLL_PRIOR_SORTED_UNIFORM: case RVLL_PRIOR_SORTED_LOGUNIFORM:
             break;
         case RVLL_PRIOR_TABLE:
             if (p.table_n < 2 || !p.table_cdf || !p.table_x)

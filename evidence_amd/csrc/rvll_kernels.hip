@@ -19,6 +19,7 @@
 // is no contraction here.
 #include "rvll_kernels.h"
 #include "rvll_math.h"
+#include "rvll_special.h"
 
 namespace rvll {
 
@@ -300,77 +301,6 @@ void loglike_kernel(const LoglikeArgs a)
 // prior transform
 // ---------------------------------------------------------------------------
 
-// Inverse normal CDF, Wichura's AS241 (PPND16), relative accuracy ~1e-16.
-__device__ double ndtri_f64(double p)
-{
-    if (!(p > 0.)) return p == 0. ? -INFINITY : NAN;
-    if (!(p < 1.)) return p == 1. ? INFINITY : NAN;
-    const double q = p - 0.5;
-    if (fabs(q) <= 0.425) {
-        const double r = 0.180625 - q * q;
-        double num = 2509.0809287301226727;
-        num = __builtin_fma(num, r, 33430.575583588128105);
-        num = __builtin_fma(num, r, 67265.770927008700853);
-        num = __builtin_fma(num, r, 45921.953931549871457);
-        num = __builtin_fma(num, r, 13731.693765509461125);
-        num = __builtin_fma(num, r, 1971.5909503065514427);
-        num = __builtin_fma(num, r, 133.14166789178437745);
-        num = __builtin_fma(num, r, 3.387132872796366608);
-        double den = 5226.495278852545925;
-        den = __builtin_fma(den, r, 28729.085735721942674);
-        den = __builtin_fma(den, r, 39307.89580009271061);
-        den = __builtin_fma(den, r, 21213.794301586595867);
-        den = __builtin_fma(den, r, 5394.1960214247511077);
-        den = __builtin_fma(den, r, 687.1870074920579083);
-        den = __builtin_fma(den, r, 42.313330701600911252);
-        den = __builtin_fma(den, r, 1.0);
-        return q * num / den;
-    }
-    double r = q < 0. ? p : 1. - p;
-    r = sqrt(-log(r));
-    double val;
-    if (r <= 5.) {
-        r -= 1.6;
-        double num = 7.7454501427834140764e-4;
-        num = __builtin_fma(num, r, 0.0227238449892691845833);
-        num = __builtin_fma(num, r, 0.24178072517745061177);
-        num = __builtin_fma(num, r, 1.27045825245236838258);
-        num = __builtin_fma(num, r, 3.64784832476320460504);
-        num = __builtin_fma(num, r, 5.7694972214606914055);
-        num = __builtin_fma(num, r, 4.6303378461565452959);
-        num = __builtin_fma(num, r, 1.42343711074968357734);
-        double den = 1.05075007164441684324e-9;
-        den = __builtin_fma(den, r, 5.475938084995344946e-4);
-        den = __builtin_fma(den, r, 0.0151986665636164571966);
-        den = __builtin_fma(den, r, 0.14810397642748007459);
-        den = __builtin_fma(den, r, 0.68976733498510000455);
-        den = __builtin_fma(den, r, 1.6763848301838038494);
-        den = __builtin_fma(den, r, 2.05319162663775882187);
-        den = __builtin_fma(den, r, 1.0);
-        val = num / den;
-    } else {
-        r -= 5.;
-        double num = 2.01033439929228813265e-7;
-        num = __builtin_fma(num, r, 2.71155556874348757815e-5);
-        num = __builtin_fma(num, r, 0.0012426609473880784386);
-        num = __builtin_fma(num, r, 0.026532189526576123093);
-        num = __builtin_fma(num, r, 0.29656057182850489123);
-        num = __builtin_fma(num, r, 1.7848265399172913358);
-        num = __builtin_fma(num, r, 5.4637849111641143699);
-        num = __builtin_fma(num, r, 6.6579046435011037772);
-        double den = 2.04426310338993978564e-15;
-        den = __builtin_fma(den, r, 1.4215117583164458887e-7);
-        den = __builtin_fma(den, r, 1.8463183175100546818e-5);
-        den = __builtin_fma(den, r, 7.868691311456132591e-4);
-        den = __builtin_fma(den, r, 0.0148753612908506148525);
-        den = __builtin_fma(den, r, 0.13692988092273580531);
-        den = __builtin_fma(den, r, 0.59983220655588793769);
-        den = __builtin_fma(den, r, 1.0);
-        val = num / den;
-    }
-    return q < 0. ? -val : val;
-}
-
 // Piecewise-linear inverse CDF on a host-built grid; the semantics of
 // scipy.interpolate.interp1d(cdf, x)(q) (which evaluates 1-D linear tables through
 // numpy.interp) as used by priors.py:118-124 and friends.
@@ -407,6 +337,24 @@ __device__ double table_ppf(const rvll_prior& pr, double q)
     return pr.table_post ? pow(10., y) : y;
 }
 
+// Forced-identifiability transform of pypolychord's SortedUniformPrior / LogSortedUniformPrior
+// (evidence/priors.py:462-467, grouped call in evidence/polychord/__init__.py:145-160):
+//   t[N-1] = x[N-1]^(1/N),  t[n] = x[n]^(1/(n+1)) t[n+1]   over the group's members in
+// parameter order, then a + (b-a) t  (or a (b/a)^t).  Every member of kind `kind` belongs to
+// the one group, and the bounds of the LAST member are used, as the wrapper does.
+__device__ double sorted_prior(const PriorArgs& a, const double* cube_row, int d, int kind)
+{
+    int rank = 0, last = d;
+    for (int k = 0; k < a.D; ++k)
+        if (a.priors[k].kind == kind) { if (k < d) ++rank; last = k; }
+    double t = 1.;
+    int n = rank;
+    for (int k = d; k < a.D; ++k)
+        if (a.priors[k].kind == kind) { t *= pow(cube_row[k], 1.0 / (double)(n + 1)); ++n; }
+    const double lo = a.priors[last].args[0], hi = a.priors[last].args[1];
+    return kind == RVLL_PRIOR_SORTED_UNIFORM ? lo + (hi - lo) * t : lo * pow(hi / lo, t);
+}
+
 __global__ __launch_bounds__(kThreads)
 void prior_kernel(const PriorArgs a)
 {
@@ -436,6 +384,15 @@ void prior_kernel(const PriorArgs a)
             v = sqrt(-2 * (sg * sg) * log(1 - (q * A))); break; }
         case RVLL_PRIOR_TABLE:
             v = table_ppf(pr, q); break;
+        case RVLL_PRIOR_BETA:                // stats.beta.ppf(q, a, b); args[2] = ln B(a,b)
+            v = beta_ppf(q, pr.args[0], pr.args[1], pr.args[2]); break;
+        case RVLL_PRIOR_GAMMA:               // stats.gamma.ppf(q, alpha, scale=1/beta); args[2] = ln Gamma(alpha)
+            v = gamma_ppf(q, pr.args[0], pr.args[1], pr.args[2]); break;
+        case RVLL_PRIOR_ALPHA:               // stats.alpha.ppf(q, a); args[1] = Phi(a)
+            v = alpha_ppf(q, pr.args[0], pr.args[1]); break;
+        case RVLL_PRIOR_SORTED_UNIFORM:
+        case RVLL_PRIOR_SORTED_LOGUNIFORM:
+            v = sorted_prior(a, a.cube + (i - d), d, pr.kind); break;
         default:
             v = NAN; break;
         }

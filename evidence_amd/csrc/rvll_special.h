@@ -1,0 +1,287 @@
+// rvll_special.h — quantile functions behind the scipy-backed priors of the reference
+// (evidence/priors.py:357-437): Normal/LogNormal (ndtri), Beta (betaincinv), Gamma
+// (gammaincinv), Alpha.  Written host+device: the prior kernel uses them on the GPU and
+// tests/native/hostmath.hip compiles the very same source for the CPU so that the
+// `-m "not gpu"` suite can compare it with scipy.
+//
+// scipy's own implementations (cephes ndtri, Boost ibeta_inv / scipy igami) are third-party
+// dependencies that are not part of the reference checkout; what is restated here is the
+// published mathematics: Wichura's AS241 for the normal quantile, and for the incomplete
+// beta/gamma inverses a bracketed Newton iteration in log space on the regularised functions,
+// which are evaluated by their classical series / continued fractions (modified Lentz).
+// Parity is anchored on golden vectors generated from the reference's .ppf calls
+// (tests/golden/priors.npz).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#ifndef RVLL_HDF
+#define RVLL_HDF __host__ __device__ inline
+#endif
+
+namespace rvll {
+
+// ---- inverse normal CDF: Wichura, Algorithm AS241 (PPND16), rel. accuracy ~1e-16 ----------
+RVLL_HDF double ndtri_f64(double p)
+{
+    if (!(p > 0.)) return p == 0. ? -INFINITY : NAN;
+    if (!(p < 1.)) return p == 1. ? INFINITY : NAN;
+    const double q = p - 0.5;
+    if (fabs(q) <= 0.425) {
+        const double r = 0.180625 - q * q;
+        double num = 2509.0809287301226727;
+        num = __builtin_fma(num, r, 33430.575583588128105);
+        num = __builtin_fma(num, r, 67265.770927008700853);
+        num = __builtin_fma(num, r, 45921.953931549871457);
+        num = __builtin_fma(num, r, 13731.693765509461125);
+        num = __builtin_fma(num, r, 1971.5909503065514427);
+        num = __builtin_fma(num, r, 133.14166789178437745);
+        num = __builtin_fma(num, r, 3.387132872796366608);
+        double den = 5226.495278852545925;
+        den = __builtin_fma(den, r, 28729.085735721942674);
+        den = __builtin_fma(den, r, 39307.89580009271061);
+        den = __builtin_fma(den, r, 21213.794301586595867);
+        den = __builtin_fma(den, r, 5394.1960214247511077);
+        den = __builtin_fma(den, r, 687.1870074920579083);
+        den = __builtin_fma(den, r, 42.313330701600911252);
+        den = __builtin_fma(den, r, 1.0);
+        return q * num / den;
+    }
+    double r = q < 0. ? p : 1. - p;
+    r = sqrt(-log(r));
+    double val;
+    if (r <= 5.) {
+        r -= 1.6;
+        double num = 7.7454501427834140764e-4;
+        num = __builtin_fma(num, r, 0.0227238449892691845833);
+        num = __builtin_fma(num, r, 0.24178072517745061177);
+        num = __builtin_fma(num, r, 1.27045825245236838258);
+        num = __builtin_fma(num, r, 3.64784832476320460504);
+        num = __builtin_fma(num, r, 5.7694972214606914055);
+        num = __builtin_fma(num, r, 4.6303378461565452959);
+        num = __builtin_fma(num, r, 1.42343711074968357734);
+        double den = 1.05075007164441684324e-9;
+        den = __builtin_fma(den, r, 5.475938084995344946e-4);
+        den = __builtin_fma(den, r, 0.0151986665636164571966);
+        den = __builtin_fma(den, r, 0.14810397642748007459);
+        den = __builtin_fma(den, r, 0.68976733498510000455);
+        den = __builtin_fma(den, r, 1.6763848301838038494);
+        den = __builtin_fma(den, r, 2.05319162663775882187);
+        den = __builtin_fma(den, r, 1.0);
+        val = num / den;
+    } else {
+        r -= 5.;
+        double num = 2.01033439929228813265e-7;
+        num = __builtin_fma(num, r, 2.71155556874348757815e-5);
+        num = __builtin_fma(num, r, 0.0012426609473880784386);
+        num = __builtin_fma(num, r, 0.026532189526576123093);
+        num = __builtin_fma(num, r, 0.29656057182850489123);
+        num = __builtin_fma(num, r, 1.7848265399172913358);
+        num = __builtin_fma(num, r, 5.4637849111641143699);
+        num = __builtin_fma(num, r, 6.6579046435011037772);
+        double den = 2.04426310338993978564e-15;
+        den = __builtin_fma(den, r, 1.4215117583164458887e-7);
+        den = __builtin_fma(den, r, 1.8463183175100546818e-5);
+        den = __builtin_fma(den, r, 7.868691311456132591e-4);
+        den = __builtin_fma(den, r, 0.0148753612908506148525);
+        den = __builtin_fma(den, r, 0.13692988092273580531);
+        den = __builtin_fma(den, r, 0.59983220655588793769);
+        den = __builtin_fma(den, r, 1.0);
+        val = num / den;
+    }
+    return q < 0. ? -val : val;
+}
+
+// ---- regularised incomplete beta ---------------------------------------------------------
+// Continued fraction of I_x(a,b) (modified Lentz); converges quickly for x < (a+1)/(a+b+2).
+RVLL_HDF double betacf(double a, double b, double x)
+{
+    const double tiny = 1e-300;
+    const double qab = a + b, qap = a + 1., qam = a - 1.;
+    double c = 1., d = 1. - qab * x / qap;
+    if (fabs(d) < tiny) d = tiny;
+    d = 1. / d;
+    double h = d;
+    for (int m = 1; m <= 400; ++m) {
+        const double m2 = 2. * m;
+        double aa = m * (b - m) * x / ((qam + m2) * (a + m2));
+        d = 1. + aa * d; if (fabs(d) < tiny) d = tiny;
+        c = 1. + aa / c; if (fabs(c) < tiny) c = tiny;
+        d = 1. / d;
+        h *= d * c;
+        aa = -(a + m) * (qab + m) * x / ((a + m2) * (qap + m2));
+        d = 1. + aa * d; if (fabs(d) < tiny) d = tiny;
+        c = 1. + aa / c; if (fabs(c) < tiny) c = tiny;
+        d = 1. / d;
+        const double del = d * c;
+        h *= del;
+        if (fabs(del - 1.) < 1e-16) break;
+    }
+    return h;
+}
+
+// ln I_x(a,b) and ln(1 - I_x(a,b)) are both needed with RELATIVE accuracy in the tails, so the
+// evaluation returns whichever of I, 1-I is computed directly by the fraction plus a flag.
+struct BetaEval { double direct; bool direct_is_lower; };   // direct = I_x if direct_is_lower else 1 - I_x
+RVLL_HDF BetaEval betainc_eval(double a, double b, double x, double lbeta)
+{
+    BetaEval r;
+    // ln of the prefactor x^a (1-x)^b / B(a,b)
+    const double lpre = a * log(x) + b * log1p(-x) - lbeta;
+    if (x < (a + 1.) / (a + b + 2.)) {
+        r.direct = exp(lpre) * betacf(a, b, x) / a;
+        r.direct_is_lower = true;
+    } else {
+        r.direct = exp(lpre) * betacf(b, a, 1. - x) / b;
+        r.direct_is_lower = false;
+    }
+    return r;
+}
+RVLL_HDF double betainc_lower(double a, double b, double x, double lbeta)
+{
+    if (!(x > 0.)) return 0.;
+    if (!(x < 1.)) return 1.;
+    const BetaEval e = betainc_eval(a, b, x, lbeta);
+    return e.direct_is_lower ? e.direct : 1. - e.direct;
+}
+
+// Solve I_x(a,b) = p for p in (0, 0.5]; returns x.  Newton on ln I in u = ln x, bracketed.
+RVLL_HDF double betaincinv_lowerhalf(double a, double b, double p, double lbeta)
+{
+    // start: leading term I ~ x^a / (a B)  ->  x0 = (p a B)^(1/a), clipped into (0,1)
+    double lx = (log(p) + log(a) + lbeta) / a;
+    if (lx < -708.) return 2.2250738585072014e-308;   // the solution underflows; Boost (scipy) returns DBL_MIN here
+    if (lx > -1e-3) lx = -1e-3;
+    // a second candidate from the mean keeps Newton out of the far tail when a is large
+    const double mean = a / (a + b);
+    double x = exp(lx);
+    if (a > 1. && x < 0.01 * mean) x = 0.5 * mean;
+    double lo = 0., hi = 1.;
+    for (int it = 0; it < 200; ++it) {
+        const BetaEval e = betainc_eval(a, b, x, lbeta);
+        const double I = e.direct_is_lower ? e.direct : 1. - e.direct;
+        if (I > p) hi = x; else lo = x;
+        // F(u) = ln I - ln p ;  dF/du = x pdf(x) / I, with x pdf = exp(lpre)/(1-x)... computed directly:
+        const double xpdf = exp(a * log(x) + (b - 1.) * log1p(-x) - lbeta);
+        double xn;
+        if (I > 0. && xpdf > 0.) {
+            const double F = (fabs(I - p) < 0.5 * p) ? log1p((I - p) / p) : log(I / p);
+            const double step = F * I / xpdf;            // du
+            xn = x * exp(-step);
+        } else {
+            xn = -1.;
+        }
+        if (!(xn >= lo && xn <= hi) || !(xn > 0.)) xn = lo > 0. ? 0.5 * (lo + hi) : 0.5 * x;   // leave Newton: bisect the bracket
+        const double dx = fabs(xn - x);
+        x = xn;
+        if (dx <= 2.5e-16 * x) break;
+    }
+    return x;
+}
+
+// scipy.stats.beta.ppf(q, a, b) through rv_continuous.ppf's front end (support [0, 1]).
+RVLL_HDF double beta_ppf(double q, double a, double b, double lbeta)
+{
+    if (q == 0.) return 0.;
+    if (q == 1.) return 1.;
+    if (!(q > 0. && q < 1.)) return NAN;
+    if (q <= 0.5) return betaincinv_lowerhalf(a, b, q, lbeta);
+    // upper half: I_x(a,b) = q  <=>  I_{1-x}(b,a) = 1 - q   (1 - q is exact for q >= 0.5)
+    return 1. - betaincinv_lowerhalf(b, a, 1. - q, lbeta);
+}
+
+// ---- regularised incomplete gamma -----------------------------------------------------------
+// P(a,x) by its power series (x < a+1), Q(a,x) by the continued fraction (x >= a+1).
+struct GammaEval { double direct; bool direct_is_lower; };
+RVLL_HDF GammaEval gammainc_eval(double a, double x, double lgam)
+{
+    GammaEval r;
+    const double lpre = a * log(x) - x - lgam;           // ln( x^a e^-x / Gamma(a) )
+    if (x < a + 1.) {
+        double ap = a, del = 1. / a, sum = del;
+        for (int n = 0; n < 2000; ++n) {
+            ap += 1.;
+            del *= x / ap;
+            sum += del;
+            if (fabs(del) < fabs(sum) * 1e-17) break;
+        }
+        r.direct = sum * exp(lpre);
+        r.direct_is_lower = true;
+    } else {
+        const double tiny = 1e-300;
+        double b = x + 1. - a, c = 1. / tiny, d = 1. / b, h = d;
+        for (int i = 1; i <= 2000; ++i) {
+            const double an = -i * (i - a);
+            b += 2.;
+            d = an * d + b; if (fabs(d) < tiny) d = tiny;
+            c = b + an / c; if (fabs(c) < tiny) c = tiny;
+            d = 1. / d;
+            const double del = d * c;
+            h *= del;
+            if (fabs(del - 1.) < 1e-16) break;
+        }
+        r.direct = exp(lpre) * h;
+        r.direct_is_lower = false;
+    }
+    return r;
+}
+
+// scipy.special.gammaincinv(a, q): x with P(a, x) = q.
+RVLL_HDF double gammaincinv(double a, double q, double lgam)
+{
+    if (q == 0.) return 0.;
+    if (q == 1.) return INFINITY;
+    if (!(q > 0. && q < 1.)) return NAN;
+    const bool lower = q <= 0.5;
+    const double p = lower ? q : 1. - q;                 // target for P (lower) or Q (upper)
+    // start: Wilson-Hilferty, else the small-x leading term P ~ x^a / Gamma(a+1)
+    double x;
+    {
+        const double z = ndtri_f64(q);
+        const double t = 1. - 1. / (9. * a) + z / (3. * sqrt(a));
+        x = a * t * t * t;
+        const double xs = exp((log(q) + lgam + log(a)) / a);
+        if (!(t > 0.) || a < 1. || x < 0.2 * a) x = (xs < 0.9 * (a + 1.)) ? xs : fmax(x, 0.5 * a);
+        if (!(x > 0.)) x = 1e-300;
+    }
+    double lo = 0., hi = INFINITY;
+    for (int it = 0; it < 200; ++it) {
+        const GammaEval e = gammainc_eval(a, x, lgam);
+        const double P = e.direct_is_lower ? e.direct : 1. - e.direct;
+        const double Q = e.direct_is_lower ? 1. - e.direct : e.direct;
+        const double val = lower ? P : Q;                // the quantity matched against p
+        const bool x_too_big = lower ? (val > p) : (val < p);
+        if (x_too_big) hi = x; else lo = x;
+        const double xpdf = exp(a * log(x) - x - lgam);  // x * pdf(x)
+        double xn = -1.;
+        if (val > 0. && xpdf > 0.) {
+            const double F = (fabs(val - p) < 0.5 * p) ? log1p((val - p) / p) : log(val / p);
+            // d ln P / d ln x = x pdf / P ;  d ln Q / d ln x = - x pdf / Q
+            const double du = lower ? F * val / xpdf : -F * val / xpdf;
+            xn = x * exp(-du);
+        }
+        if (!(xn >= lo && xn <= hi) || !(xn > 0.))
+            xn = (hi < INFINITY) ? (lo > 0. ? 0.5 * (lo + hi) : 0.5 * x) : 2. * x;
+        const double dx = fabs(xn - x);
+        x = xn;
+        if (dx <= 2.5e-16 * x) break;
+    }
+    return x;
+}
+
+// scipy.stats.gamma.ppf(q, alpha, scale = 1/beta) (evidence/priors.py:424-425)
+RVLL_HDF double gamma_ppf(double q, double alpha, double beta, double lgam)
+{
+    return gammaincinv(alpha, q, lgam) * (1.0 / beta);
+}
+
+// scipy.stats.alpha.ppf(q, a) = 1 / (a - ndtri(q * Phi(a)))   (Phi(a) precomputed on the host)
+RVLL_HDF double alpha_ppf(double q, double a, double phi_a)
+{
+    if (q == 0.) return 0.;
+    if (q == 1.) return INFINITY;
+    if (!(q > 0. && q < 1.)) return NAN;
+    return 1.0 / (a - ndtri_f64(q * phi_a));
+}
+
+}  // namespace rvll

@@ -13,6 +13,7 @@ Table-inverted priors (evidence/priors.py:118-124, 195-202, 223-228, 282-287,
 built once at construction (`numpy.arange` with the same arguments, `scipy.special.ndtr`
 for the normal CDF — the function `scipy.stats.norm.cdf` evaluates) and uploaded.
 """
+import math
 from dataclasses import dataclass, field
 from typing import Optional, Tuple
 
@@ -105,17 +106,18 @@ def LogNormal(s, loc=0.0, scale=1.0):            # :437  (= scipy.stats.lognorm)
 
 def Beta(a, b):                                  # :378-398 (scipy.stats.beta.ppf)
     _require(a > 0 and b > 0, "Beta", "needs a > 0 and b > 0")
-    return PriorSpec("Beta", _abi.PRIOR_BETA, _f(a, b))
+    lbeta = math.lgamma(a) + math.lgamma(b) - math.lgamma(a + b)     # setup-time constant for the kernel
+    return PriorSpec("Beta", _abi.PRIOR_BETA, _f(a, b, lbeta))
 
 
 def Gamma(alpha, beta):                          # :400-425 (scipy.stats.gamma.ppf, scale = 1/beta)
     _require(alpha > 0 and beta > 0, "Gamma", "needs alpha > 0 and beta > 0")
-    return PriorSpec("Gamma", _abi.PRIOR_GAMMA, _f(alpha, beta))
+    return PriorSpec("Gamma", _abi.PRIOR_GAMMA, _f(alpha, beta, math.lgamma(alpha)))
 
 
 def Alpha(a):                                    # :357-376 (scipy.stats.alpha.ppf)
     _require(a > 0, "Alpha", "needs a > 0")
-    return PriorSpec("Alpha", _abi.PRIOR_ALPHA, _f(a))
+    return PriorSpec("Alpha", _abi.PRIOR_ALPHA, _f(a, 0.5 * math.erfc(-a / math.sqrt(2.0))))   # Phi(a)
 
 
 # ---- table-inverted families -----------------------------------------------------------

@@ -1,0 +1,96 @@
+"""GPU parity: the device prior transform (rvll_prior_batch) against the golden vectors produced by the
+reference's own `.ppf` for every distribution of evidence/priors.py, plus the fused prior+log-L call."""
+import numpy as np
+import pytest
+
+import golden
+import prior_cases as pc
+from evidence_amd import GpuRVModel, priors as P
+from evidence_amd.data import EpochTable
+from evidence_amd.synthetic import make_workload
+
+pytestmark = pytest.mark.gpu
+Q, SETS = golden.prior_sets()
+
+
+def one_param_model(spec):
+    """A model with a single free parameter (an instrument offset) carrying the prior under test."""
+    table = EpochTable.from_arrays(["ia"], [50000.0, 50001.0], [1.0, -1.0], [1.0, 1.0], [0, 0])
+    return GpuRVModel({}, table, ["ia_offset"], priordict={"ia_offset": spec})
+
+
+@pytest.mark.parametrize("name,args,vals,raised", SETS, ids=[f"{n}{tuple(a)}" for n, a, _, _ in SETS])
+def test_device_ppf_matches_reference(gpu_required, name, args, vals, raised):
+    with one_param_model(pc.spec_for(name, args)) as m:
+        got = m.prior_transform_batch(Q.reshape(-1, 1))[:, 0]
+    mask = pc.comparable_mask(name, Q, raised)
+    err = pc.rel_err(got[mask], vals[mask])
+    assert err.max() <= pc.TOL.get(name, pc.DEFAULT_TOL), (name, args, float(err.max()), float(Q[mask][err.argmax()]))
+    assert np.all(np.isnan(got[raised]))            # where the reference raises ValueError we return NaN
+
+
+def test_reference_unit_test_uniform(gpu_required):
+    # tests/test_priors.py:13-15
+    with one_param_model(P.Uniform(4, 6)) as m:
+        assert m.prior_transform(np.array([0.5]))[0] == 5 and m.prior_transform(np.array([0.0]))[0] == 4
+        assert m.prior_transform(np.array([1.0]))[0] == 6
+
+
+def test_known_51peg_prior_vector(gpu_required):
+    """prior(cube = 0.37) on the shipped 51Peg config."""
+    z = np.load(golden.GOLDEN / "loglike_51peg.npz")
+    table = EpochTable.from_arrays(["hamilton"], z["time"], z["vrad"], z["svrad"], z["inst_id"])
+    pri = {"hamilton_jitter": P.Uniform(0.0, 50.0), "hamilton_offset": P.Uniform(-10, 10),
+           "planet1_ecc": P.Beta(0.867, 3.03), "planet1_k1": P.Jeffreys(0.1, 100.0),
+           "planet1_ma0": P.Uniform(0.0, 2 * np.pi), "planet1_omega": P.Uniform(0.0, 2 * np.pi),
+           "planet1_period": P.UniformFrequency(1, 100)}
+    want = [18.5, -2.5999999999999996, 0.11465599401597197, 1.288249551693134, 2.324778563656447,
+            2.324778563656447, 1.5780337699226765]
+    with GpuRVModel({"planet1_epoch": 51050.0}, table, list(pri), priordict=pri) as m:
+        got = m.prior_transform(np.full(7, 0.37))
+    assert pc.rel_err(got, want).max() <= 1e-13
+
+
+def test_fused_prior_loglike_equals_two_calls(gpu_required):
+    w = make_workload(3)
+    cube = w.sample_cube(4096, seed=11)
+    with GpuRVModel(w.fixedpardict, w.table, w.parnames, priordict=w.priordict()) as m:
+        theta, logl = m.prior_loglike_batch(cube)
+        theta2 = m.prior_transform_batch(cube)
+        logl2 = m.log_likelihood_batch(theta2)
+    assert np.array_equal(theta, theta2) and np.array_equal(logl, logl2)
+    assert np.all((theta[:, w.parnames.index("planet1_ecc")] >= 0) & (theta[:, w.parnames.index("planet1_ecc")] <= 1))
+
+
+def test_prior_before_set_priors_is_an_error(gpu_required):
+    from evidence_amd import RvllError
+    w = make_workload(1)
+    with GpuRVModel(w.fixedpardict, w.table, w.parnames) as m:
+        with pytest.raises(RvllError):
+            m.prior_transform_batch(w.sample_cube(4, 0))
+
+
+def test_sorted_uniform_forced_identifiability(gpu_required):
+    """pypolychord's SortedUniformPrior is absent from the reference checkout (parity unpinned);
+    checked against the documented transform t[N-1]=x[N-1]^(1/N), t[n]=x[n]^(1/(n+1)) t[n+1]."""
+    table = EpochTable.from_arrays(["ia"], [50000.0, 50001.0], [1.0, -1.0], [1.0, 1.0], [0, 0])
+    names = ["planet1_period", "planet2_period", "planet3_period", "ia_offset"]
+    fixed = {}
+    for n in (1, 2, 3):
+        fixed.update({f"planet{n}_k1": 1.0, f"planet{n}_ecc": 0.0, f"planet{n}_omega": 0.0, f"planet{n}_ma0": 0.0,
+                      f"planet{n}_epoch": 0.0})
+    pri = {"planet1_period": P.SortedUniform(1.0, 100.0), "planet2_period": P.SortedUniform(1.0, 100.0),
+           "planet3_period": P.SortedUniform(1.0, 100.0), "ia_offset": P.Uniform(-1, 1)}
+    rng = np.random.default_rng(0)
+    cube = rng.random((500, 4))
+    with GpuRVModel(fixed, table, names, priordict=pri) as m:
+        idx = [m.parnames.index(f"planet{n}_period") for n in (1, 2, 3)]
+        got = m.prior_transform_batch(cube)
+    x = cube[:, idx]
+    t = np.empty_like(x)
+    t[:, 2] = x[:, 2] ** (1 / 3)
+    t[:, 1] = x[:, 1] ** (1 / 2) * t[:, 2]
+    t[:, 0] = x[:, 0] ** (1 / 1) * t[:, 1]
+    want = 1.0 + 99.0 * t
+    assert pc.rel_err(got[:, idx], want).max() <= 1e-14
+    assert np.all(np.diff(got[:, idx], axis=1) >= 0)          # sorted: that is the point of the prior
