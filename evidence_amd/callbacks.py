@@ -1,0 +1,56 @@
+"""The drop-in boundary: `prior(cube)` / `loglike(theta)` closures with exactly the
+signatures and return conventions the reference hands to its samplers.
+
+  make_polychord_callbacks  evidence/polychord/__init__.py:130-171
+        prior(hypercube) -> new 1-D float64 array theta (sorted-prior groups transformed together)
+        loglike(x)       -> (float logL, [])          # second element = derived parameters, nderived = 0
+        call site: run_polychord(loglike, ndim, nderived, settings, prior)          (:190)
+  make_ultranest_callbacks  evidence/ultranest/__init__.py:125-146
+        prior(hypercube) -> new 1-D float64 array theta
+        loglike(x)       -> float
+        call site: ReactiveNestedSampler(parnames, loglike, prior, ..., wrapped_params=...)  (:165-172)
+        with vectorized=True (the switch the reference left commented at :171) the same closures
+        accept (n, ndim) arrays and return (n, ndim) / (n,) — the form that feeds the GPU.
+
+Everything evaluates on the GPU through GpuRVModel; nothing here computes a likelihood.
+"""
+from typing import Callable, Sequence, Tuple
+
+import numpy as np
+
+
+def wrapped_params(parnames: Sequence[str]) -> np.ndarray:
+    """Circular parameters, as evidence/ultranest/__init__.py:159-163 flags them."""
+    return np.array([("omega" in p) or ("ml0" in p) for p in parnames], dtype=bool)
+
+
+def make_polychord_callbacks(model) -> Tuple[Callable, Callable, int, int]:
+    """(prior, loglike, ndim, nderived) for pypolychord.run_polychord."""
+    ndim, nderived = len(model.parnames), 0
+
+    def prior(hypercube):
+        cube = np.asarray(hypercube, dtype=np.float64)
+        return model.prior_transform(cube)
+
+    def loglike(x):
+        return (model.log_likelihood(x), [])
+
+    return prior, loglike, ndim, nderived
+
+
+def make_ultranest_callbacks(model, vectorized: bool = False) -> Tuple[Callable, Callable]:
+    """(prior, loglike) for ultranest.ReactiveNestedSampler(parnames, loglike, prior, vectorized=...)."""
+    if vectorized:
+        def prior(hypercubes):
+            return model.prior_transform_batch(np.asarray(hypercubes, dtype=np.float64))
+
+        def loglike(thetas):
+            return model.log_likelihood_batch(np.asarray(thetas, dtype=np.float64))
+    else:
+        def prior(hypercube):
+            return model.prior_transform(np.asarray(hypercube, dtype=np.float64))
+
+        def loglike(x):
+            return model.log_likelihood(x)
+
+    return prior, loglike

@@ -1,0 +1,85 @@
+"""Multi-GPU: live points shard across ranks (one process per GPU); one all-gather of the
+per-shard log-L returns every value to every rank — in particular to rank 0, which owns the
+sampler's replacement step.  This replaces the MPI fan-out the reference leaves to its third-party
+samplers (evidence/polychord/__init__.py:21-29,176-199; evidence/ultranest/__init__.py:21-29,151-194);
+there is no other exchange on this path, so there is no other collective.
+
+Two transports for the same partition:
+  "rccl"  the device buffer the log-L kernel wrote is all-gathered in place by RCCL over xGMI on the
+          handle's comm stream (rvll_allgather_logl) — the product path on a GPU node;
+  "dist"  torch.distributed all_gather of host buffers (gloo) — used by the CPU tests of the sharding
+          logic, and as a transport fallback if RCCL cannot be initialised.
+The evaluation itself is always whatever `evaluate` is: GpuRVModel.log_likelihood_batch in the product.
+"""
+from typing import Callable, List, Tuple
+
+import numpy as np
+
+
+def partition(n_points: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous, near-even row ranges [lo, hi) per rank; the first n_points % world ranks get one more."""
+    if world < 1 or n_points < 0:
+        raise ValueError("world >= 1 and n_points >= 0 required")
+    base, extra = divmod(n_points, world)
+    out, lo = [], 0
+    for r in range(world):
+        hi = lo + base + (1 if r < extra else 0)
+        out.append((lo, hi))
+        lo = hi
+    return out
+
+
+def padded_count(n_points: int, world: int) -> int:
+    """All-gather needs equal counts: every rank contributes ceil(n/world) slots."""
+    return -(-n_points // world) if n_points else 0
+
+
+def unpad(gathered: np.ndarray, n_points: int, world: int) -> np.ndarray:
+    """[world * padded] rank-major -> [n_points] in original row order."""
+    pad = padded_count(n_points, world)
+    g = np.asarray(gathered).reshape(world, pad) if pad else np.empty((world, 0))
+    return np.concatenate([g[r, : hi - lo] for r, (lo, hi) in enumerate(partition(n_points, world))]) \
+        if n_points else np.empty(0)
+
+
+class ShardedLogLike:
+    """loglike over a batch every rank holds (replicated theta): each rank evaluates its rows, then
+    one all-gather.  Returns the full [n] log-L vector on every rank."""
+
+    def __init__(self, rank: int, world: int, evaluate: Callable[[np.ndarray], np.ndarray] = None,
+                 model=None, transport: str = "dist"):
+        if transport not in ("dist", "rccl"):
+            raise ValueError(transport)
+        if transport == "rccl" and model is None:
+            raise ValueError("the rccl transport gathers the model's device buffer: pass model=")
+        if evaluate is None and model is None:
+            raise ValueError("pass evaluate= or model=")
+        self.rank, self.world, self.model, self.transport = rank, world, model, transport
+        self.evaluate = evaluate if evaluate is not None else model.log_likelihood_batch
+
+    def __call__(self, theta: np.ndarray) -> np.ndarray:
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        n = theta.shape[0]
+        lo, hi = partition(n, self.world)[self.rank]
+        pad = padded_count(n, self.world)
+        if n == 0:
+            return np.empty(0)
+        shard = theta[lo:hi]
+        if self.transport == "rccl":
+            m = self.model
+            rows = np.zeros((pad, theta.shape[1]))
+            rows[: hi - lo] = shard
+            if hi - lo < pad:                      # padding rows: repeat a real row so the kernel sees sane input
+                rows[hi - lo:] = theta[lo] if hi > lo else theta[0]
+            m.dev_upload_theta(rows)
+            m.dev_loglike(pad)
+            m.allgather_logl(pad)
+            return unpad(m.download_gathered(self.world * pad), n, self.world)
+        import torch
+        import torch.distributed as dist
+        mine = torch.zeros(pad, dtype=torch.float64)
+        if hi > lo:
+            mine[: hi - lo] = torch.from_numpy(np.asarray(self.evaluate(shard), dtype=np.float64))
+        parts = [torch.empty(pad, dtype=torch.float64) for _ in range(self.world)]
+        dist.all_gather(parts, mine)
+        return unpad(torch.cat(parts).numpy(), n, self.world)

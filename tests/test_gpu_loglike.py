@@ -10,7 +10,7 @@ import golden
 from evidence_amd import GpuRVModel, FLAG_INVALID_ORBIT
 from evidence_amd.synthetic import make_workload
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(180)]
 TOL = 1e-10     # BASELINE.json north_star: <= 1e-10 relative on identical theta
 
 CASES = golden.all_loglike_cases()

@@ -5,7 +5,7 @@ import pytest
 from evidence_amd import GpuRVModel
 from evidence_amd.synthetic import make_workload
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(180)]
 ULP1 = 2.0 ** -53      # half-ulp of values in [1, 2) == one ulp of values in [0.5, 1)
 
 

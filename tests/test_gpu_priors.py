@@ -9,7 +9,7 @@ from evidence_amd import GpuRVModel, priors as P
 from evidence_amd.data import EpochTable
 from evidence_amd.synthetic import make_workload
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(180)]
 Q, SETS = golden.prior_sets()
 
 

@@ -1,0 +1,42 @@
+"""CPU: the batched nested-sampling driver on the reference's Gaussian known-answer problems
+(tests/test_polychord.py:75-151 with tests/test_examples/gaussian/*: unnormalised likelihood
+-1/2 sum x^2 under Uniform(-10, 10) priors; analytic ln Z = ln(sqrt(2 pi)/20) per dimension)."""
+import numpy as np
+import pytest
+
+from evidence_amd.nested import run_nested
+
+LNZ_1D = float(np.log(np.sqrt(2 * np.pi) / 20.0))       # -2.0768
+
+
+@pytest.mark.parametrize("ndim,nlive", [(1, 100), (2, 500)])
+def test_gaussian_logz_known_answer(ndim, nlive):
+    prior = lambda cube: -10.0 + 20.0 * cube                       # Uniform(-10, 10).ppf, vectorized
+    loglike = lambda x: -0.5 * np.sum(x * x, axis=1)
+    res = run_nested(prior, loglike, ndim, nlive=nlive, dlogz=0.05, seed=1)
+    want = ndim * LNZ_1D
+    assert abs(res.logz - want) < 0.5                               # the reference's own tolerance (:98, :139)
+    assert abs(res.logz - want) < 4 * res.logzerr + 0.05
+    w = np.exp(res.logwt)
+    assert abs(w.sum() - 1) < 1e-9
+    mean = (w[:, None] * res.samples).sum(axis=0)
+    var = (w[:, None] * (res.samples - mean) ** 2).sum(axis=0)
+    assert np.all(np.abs(mean) < 0.3) and np.all(np.abs(var - 1) < 0.35)
+    assert res.ncall >= res.niter
+
+
+def test_callbacks_are_called_with_batches():
+    seen = []
+    def loglike(x):
+        seen.append(x.shape)
+        return -0.5 * np.sum(x * x, axis=1)
+    run_nested(lambda c: -10 + 20 * c, loglike, 2, nlive=50, dlogz=0.5, seed=2, batch=256)
+    assert seen[0] == (50, 2) and all(len(s) == 2 and s[1] == 2 for s in seen)
+    assert max(s[0] for s in seen) > 50
+
+
+def test_max_calls_bounds_a_collapsing_run():
+    # a likelihood spike the ellipsoid sampler cannot find efficiently: the call budget must end the run
+    loglike = lambda x: -0.5 * np.sum(((x - 3.3) / 1e-4) ** 2, axis=1)
+    res = run_nested(lambda c: -10 + 20 * c, loglike, 3, nlive=50, dlogz=0.01, seed=3, batch=64, max_calls=3000)
+    assert res.ncall <= 3000 + 64 and np.isfinite(res.logz)
