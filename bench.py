@@ -110,6 +110,21 @@ def cpu_baseline(w, layout, theta, gpu_logl, seconds):
     }, float(err.max()), float(iters.mean())
 
 
+def pmc_traffic(cfg, batch):
+    """HBM bytes per launch of the log-L kernel from the committed rocprofv3 PMC passes
+    (profiles/pmc_traffic.json, written by scripts/profile_gpu.sh + scripts/pmc_summary.py):
+    FETCH_SIZE and WRITE_SIZE are in KiB; gfx950 reports half the bytes of a coalesced read stream, so
+    the read side is doubled (MI355X_MICROARCH.md, HBM section).  None when no matching profile exists."""
+    path = REPO / "profiles" / "pmc_traffic.json"
+    try:
+        rec = json.loads(path.read_text())
+    except (OSError, ValueError):
+        return None
+    if rec.get("cfg") != cfg or rec.get("batch") != batch:
+        return None
+    return (2.0 * rec["fetch_kib"] + rec["write_kib"]) * 1024.0
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -186,13 +201,31 @@ def main():
                        "instruments": len(w.table.insts), "free_parameters": w.ndim,
                        "parallelism": f"live-point shards x{world}", "allgather": gather},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.config, B),
                          "kernel": "loglike_kernel", "kernel_ms_mean": tm["kernel_ms_mean"],
                          "kernel_ms_min": tm["kernel_ms_min"], "algorithmic_bytes_per_launch": abytes,
                          "points_per_block": tm["points_per_block"], "blocks": tm["blocks"],
                          "kernel_evals_per_s": B / kern_s,
                          "note": "fused kernel is fp64-VALU bound, not HBM bound (DESIGN.md); see valu_fp64"},
         }
+        if world == 1:
+            # extras (never `value`): PCIe-inclusive host round trip, and cube -> theta -> log-L all on device
+            model.log_likelihood_batch(theta)
+            t1 = time.perf_counter()
+            for _ in range(10):
+                model.log_likelihood_batch(theta)
+            out["host_roundtrip_evals_per_s"] = 10 * B / (time.perf_counter() - t1)
+            model.set_priors(w.priordict())
+            model.dev_fill_cube(B, seed=99)
+            for _ in range(5):
+                model.dev_prior(B); model.dev_loglike(B)
+            model.dev_sync()
+            t1 = time.perf_counter()
+            for _ in range(50):
+                model.dev_prior(B); model.dev_loglike(B)
+            model.dev_sync()
+            out["prior_plus_loglike_evals_per_s"] = 50 * B / (time.perf_counter() - t1)
+            model.dev_upload_theta(theta)
         if not args.no_cpu and world == 1:
             cpu, perr, mean_it = cpu_baseline(w, model.layout, theta, gpu_logl, args.cpu_seconds)
             out["cpu_baseline"] = cpu

@@ -120,6 +120,8 @@ struct rvll_handle {
     // priors
     bool have_priors = false;
     rvll_prior* d_priors = nullptr;
+    int32_t* d_heavy = nullptr;
+    int n_heavy = 0;
     std::vector<double*> d_tables;
 
     // batch buffers
@@ -292,6 +294,8 @@ void free_priors(rvll_handle* h)
     for (double*& p : h->d_tables) dev_free(p);
     h->d_tables.clear();
     dev_free(h->d_priors);
+    dev_free(h->d_heavy);
+    h->n_heavy = 0;
     h->have_priors = false;
 }
 
@@ -483,6 +487,14 @@ int rvll_set_priors(rvll_handle* h, const rvll_prior* priors, int32_t ndim)
     }
     HIP_TRY(hipMalloc(&h->d_priors, sizeof(rvll_prior) * (size_t)std::max(1, ndim)));
     if (ndim) HIP_TRY(hipMemcpy(h->d_priors, dev.data(), sizeof(rvll_prior) * (size_t)ndim, hipMemcpyHostToDevice));
+    std::vector<int32_t> heavy;
+    for (int d = 0; d < ndim; ++d)
+        if (priors[d].kind == RVLL_PRIOR_BETA || priors[d].kind == RVLL_PRIOR_GAMMA) heavy.push_back(d);
+    if (!heavy.empty()) {
+        HIP_TRY(hipMalloc(&h->d_heavy, sizeof(int32_t) * heavy.size()));
+        HIP_TRY(hipMemcpy(h->d_heavy, heavy.data(), sizeof(int32_t) * heavy.size(), hipMemcpyHostToDevice));
+    }
+    h->n_heavy = (int)heavy.size();
     h->have_priors = true;
     return RVLL_OK;
 }
@@ -534,7 +546,7 @@ int rvll_dev_prior(rvll_handle* h, int64_t B)
     if (rc) return rc;
     if (!h->have_priors) return fail(RVLL_E_NOPRIORS, "rvll_set_priors has not been called");
     if (B < 0 || B > h->cap) return fail(RVLL_E_INVALID, "B %lld outside reserved capacity %lld", (long long)B, h->cap);
-    rvll::PriorArgs a{h->d_cube, h->d_theta, (long long)B, h->L.ndim, h->d_priors};
+    rvll::PriorArgs a{h->d_cube, h->d_theta, (long long)B, h->L.ndim, h->d_priors, h->d_heavy, h->n_heavy};
     HIP_TRY(rvll::launch_prior(a, h->compute));
     return RVLL_OK;
 }

@@ -53,6 +53,8 @@ struct PriorArgs {
     long long     B;
     int           D;
     const rvll_prior* priors;  // [D] device copy; table pointers are device pointers
+    const int32_t* heavy_dims; // [n_heavy] parameters whose quantile is an iterative solve (Beta, Gamma)
+    int           n_heavy;
 };
 hipError_t launch_prior(const PriorArgs& a, hipStream_t stream);
 

@@ -355,6 +355,8 @@ __device__ double sorted_prior(const PriorArgs& a, const double* cube_row, int d
     return kind == RVLL_PRIOR_SORTED_UNIFORM ? lo + (hi - lo) * t : lo * pow(hi / lo, t);
 }
 
+// Light kinds: a handful of instructions (or one table search) per element; one thread per
+// (live point, parameter), grid-stride.  Iterative kinds are left to prior_heavy_kernel.
 __global__ __launch_bounds__(kThreads)
 void prior_kernel(const PriorArgs a)
 {
@@ -384,19 +386,39 @@ void prior_kernel(const PriorArgs a)
             v = sqrt(-2 * (sg * sg) * log(1 - (q * A))); break; }
         case RVLL_PRIOR_TABLE:
             v = table_ppf(pr, q); break;
-        case RVLL_PRIOR_BETA:                // stats.beta.ppf(q, a, b); args[2] = ln B(a,b)
-            v = beta_ppf(q, pr.args[0], pr.args[1], pr.args[2]); break;
-        case RVLL_PRIOR_GAMMA:               // stats.gamma.ppf(q, alpha, scale=1/beta); args[2] = ln Gamma(alpha)
-            v = gamma_ppf(q, pr.args[0], pr.args[1], pr.args[2]); break;
         case RVLL_PRIOR_ALPHA:               // stats.alpha.ppf(q, a); args[1] = Phi(a)
             v = alpha_ppf(q, pr.args[0], pr.args[1]); break;
         case RVLL_PRIOR_SORTED_UNIFORM:
         case RVLL_PRIOR_SORTED_LOGUNIFORM:
             v = sorted_prior(a, a.cube + (i - d), d, pr.kind); break;
+        case RVLL_PRIOR_BETA:
+        case RVLL_PRIOR_GAMMA:
+            continue;                        // prior_heavy_kernel
         default:
             v = NAN; break;
         }
         a.theta[i] = v;
+    }
+}
+
+// Iterative quantiles (bracketed Newton on the regularised incomplete beta / gamma): only the
+// parameters that need them, compacted so that every lane of a wave is doing a solve.
+__global__ __launch_bounds__(kThreads)
+void prior_heavy_kernel(const PriorArgs a)
+{
+    const long long n = a.B * a.n_heavy;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n;
+         i += (long long)gridDim.x * kThreads) {
+        const long long b = i / a.n_heavy;
+        const int d = a.heavy_dims[(int)(i - b * a.n_heavy)];
+        const rvll_prior& pr = a.priors[d];
+        const double q = a.cube[b * a.D + d];
+        double v;
+        if (pr.kind == RVLL_PRIOR_BETA)      // stats.beta.ppf(q, a, b); args[2] = ln B(a,b)
+            v = beta_ppf(q, pr.args[0], pr.args[1], pr.args[2]);
+        else                                 // stats.gamma.ppf(q, alpha, scale=1/beta); args[2] = ln Gamma(alpha)
+            v = gamma_ppf(q, pr.args[0], pr.args[1], pr.args[2]);
+        a.theta[b * a.D + d] = v;
     }
 }
 
@@ -473,6 +495,11 @@ hipError_t launch_prior(const PriorArgs& a, hipStream_t stream)
     long long blocks = (n + kThreads - 1) / kThreads;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(prior_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || a.n_heavy <= 0) return e;
+    long long hb = (a.B * a.n_heavy + kThreads - 1) / kThreads;
+    if (hb > 8192) hb = 8192;
+    hipLaunchKernelGGL(prior_heavy_kernel, dim3((unsigned)hb), dim3(kThreads), 0, stream, a);
     return hipGetLastError();
 }
 

@@ -157,7 +157,9 @@ RVLL_HDF double betaincinv_lowerhalf(double a, double b, double p, double lbeta)
     double x = exp(lx);
     if (a > 1. && x < 0.01 * mean) x = 0.5 * mean;
     double lo = 0., hi = 1.;
-    for (int it = 0; it < 200; ++it) {
+    int polish = 0;       // the evaluation noise (~1e-15 relative) makes the last steps jitter by a few ulp:
+                          // once a step is below 1e-12 relative allow two more, then stop
+    for (int it = 0; it < 64; ++it) {
         const BetaEval e = betainc_eval(a, b, x, lbeta);
         const double I = e.direct_is_lower ? e.direct : 1. - e.direct;
         if (I > p) hi = x; else lo = x;
@@ -174,7 +176,8 @@ RVLL_HDF double betaincinv_lowerhalf(double a, double b, double p, double lbeta)
         if (!(xn >= lo && xn <= hi) || !(xn > 0.)) xn = lo > 0. ? 0.5 * (lo + hi) : 0.5 * x;   // leave Newton: bisect the bracket
         const double dx = fabs(xn - x);
         x = xn;
-        if (dx <= 2.5e-16 * x) break;
+        if (dx <= 4.5e-16 * x) break;
+        if (dx <= 1e-12 * x && ++polish >= 2) break;
     }
     return x;
 }
@@ -245,7 +248,8 @@ RVLL_HDF double gammaincinv(double a, double q, double lgam)
         if (!(x > 0.)) x = 1e-300;
     }
     double lo = 0., hi = INFINITY;
-    for (int it = 0; it < 200; ++it) {
+    int polish = 0;
+    for (int it = 0; it < 96; ++it) {
         const GammaEval e = gammainc_eval(a, x, lgam);
         const double P = e.direct_is_lower ? e.direct : 1. - e.direct;
         const double Q = e.direct_is_lower ? 1. - e.direct : e.direct;
@@ -264,7 +268,8 @@ RVLL_HDF double gammaincinv(double a, double q, double lgam)
             xn = (hi < INFINITY) ? (lo > 0. ? 0.5 * (lo + hi) : 0.5 * x) : 2. * x;
         const double dx = fabs(xn - x);
         x = xn;
-        if (dx <= 2.5e-16 * x) break;
+        if (dx <= 4.5e-16 * x) break;
+        if (dx <= 1e-12 * x && ++polish >= 2) break;
     }
     return x;
 }
