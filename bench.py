@@ -110,6 +110,14 @@ def cpu_baseline(w, layout, theta, gpu_logl, seconds):
     }, float(err.max()), float(iters.mean())
 
 
+def device_count():
+    import ctypes
+    from evidence_amd import _abi
+    n = ctypes.c_int32(0)
+    _abi.load().rvll_device_count(ctypes.byref(n))
+    return n.value
+
+
 def pmc_traffic(cfg, batch):
     """HBM bytes per launch of the log-L kernel from the committed rocprofv3 PMC passes
     (profiles/pmc_traffic.json, written by scripts/profile_gpu.sh + scripts/pmc_summary.py):
@@ -143,22 +151,52 @@ def main():
     w = make_workload(args.config)
     B = args.batch or (CONFIGS[args.config]["batch"] // (8 if args.config in (4, 5) else 1))
     theta = w.sample_theta(B, seed=1234 + rank)
-    model = GpuRVModel(w.fixedpardict, w.table, w.parnames, device=local_rank)
+    ndev = device_count()
+    if ndev < 1:
+        sys.exit("bench.py: no HIP device visible; evidence_amd has no CPU path")
+    if local_rank >= ndev:
+        print(f"[rank {rank}] only {ndev} device(s) visible: sharing device {local_rank % ndev} "
+              f"(rehearsal only - RCCL refuses two ranks on one GPU and the gloo transport is used)", file=sys.stderr)
+    model = GpuRVModel(w.fixedpardict, w.table, w.parnames, device=local_rank % ndev)
     if args.points_per_block:
         model.set_points_per_block(args.points_per_block)
     model.dev_upload_theta(theta)                # inputs resident in HBM before the timed region
 
     gather = "none"
     if world > 1:
-        ids = [GpuRVModel.comm_unique_id() if rank == 0 else None]
+        import torch
+        # RCCL communicator over the GPUs of this node: rank 0 creates the 128-byte id, the launcher's
+        # store carries it.  Every rank reports whether its init worked; if ANY failed, all ranks fall
+        # back to gathering the downloaded log-L over gloo (a slower TRANSPORT, same kernel), so the run
+        # still completes and says so in `config.allgather`.
+        ok = 1
+        try:
+            ids = [GpuRVModel.comm_unique_id() if rank == 0 else None]
+        except Exception as exc:                       # noqa: BLE001 - reported below
+            ids, ok = [None], 0
+            print(f"[rank {rank}] RCCL unavailable: {exc}", file=sys.stderr)
         dist.broadcast_object_list(ids, src=0)
-        model.comm_init(ids[0], world, rank)
-        gather = "rccl"
+        if ok and ids[0] is not None:
+            try:
+                model.comm_init(ids[0], world, rank)
+            except Exception as exc:                   # noqa: BLE001
+                ok = 0
+                print(f"[rank {rank}] rvll_comm_init failed: {exc}", file=sys.stderr)
+        else:
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        gather = "rccl" if int(flag.item()) == 1 else "gloo-host-fallback"
+        if gather != "rccl":
+            host_parts = [torch.empty(B, dtype=torch.float64) for _ in range(world)]
 
     def step():
         model.dev_loglike(B)
-        if world > 1:
+        if gather == "rccl":
             model.allgather_logl(B)
+        elif gather == "gloo-host-fallback":
+            _, mine, _ = model.dev_download(B)
+            dist.all_gather(host_parts, torch.from_numpy(mine))
 
     for _ in range(args.warmup):
         step()
@@ -173,14 +211,14 @@ def main():
     elapsed = time.perf_counter() - t0
     if dist:
         dist.barrier()
-        import torch
         tmax = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
     if world > 1:                                # every rank holds all N*B log-L values
-        allv = model.download_gathered(world * B)
         _, mine, _ = model.dev_download(B)
+        allv = (model.download_gathered(world * B) if gather == "rccl"
+                else np.concatenate([p.numpy() for p in host_parts]))
         assert np.array_equal(allv[rank * B:(rank + 1) * B], mine), "all-gather slot mismatch"
 
     if rank == 0:
@@ -238,7 +276,7 @@ def main():
                                             "kepler_solves_per_s": B / kern_s * len(model.layout.planets) * w.table.n_epochs}
         print(json.dumps(out), flush=True)
 
-    if world > 1:
+    if gather == "rccl":
         model.comm_destroy()
     model.close()
     if dist:
