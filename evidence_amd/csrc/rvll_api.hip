@@ -215,8 +215,14 @@ int choose_points_per_block(rvll_handle* h, long long B)
 {
     if (h->pb_override > 0) return std::min(h->pb_override, rvll::kMaxPointsPerBlock);
     if (h->geo_B == B) return h->geo_pb;
+    // Cost model fitted to the MI355X sweeps in profiles/r01_sweep_configs.txt.  A workgroup costs its CU
+    // W = ceil(PB*Ne/64)/4 wave-rounds per SIMD (a partly filled last round only occupies the waves that
+    // have items), plus ~0.6 for staging, decode, barriers and the reduction, plus ~0.5 per extra LDS
+    // window when PB*Ne exceeds it.  Workgroups are dealt round-robin and run in residency rounds of
+    // up to `occ` per CU; a round with fewer than 4 workgroups per CU hides latency worse; and the
+    // kernel ends with a tail of about half of one workgroup's duration (step-count imbalance), which
+    // favours more, shorter workgroups.
     const int Ne = h->Ne;
-    const int T = rvll::kThreads;
     int best = 1;
     double best_cost = 1e300;
     for (int pb = 1; pb <= rvll::kMaxPointsPerBlock; ++pb) {
@@ -224,14 +230,17 @@ int choose_points_per_block(rvll_handle* h, long long B)
         const size_t lds = lds_bytes_for(h, pb);
         if (pb > 1 && lds > 60 * 1024) break;
         const long long items = (long long)pb * Ne;
-        const double rounds = (double)((items + T - 1) / T);
+        const double chunks = std::ceil((double)items / h->chunk_items);
+        const double W = (double)((items + rvll::kWave - 1) / rvll::kWave) / 4.0 + 0.6 + 0.5 * (chunks - 1.0);
         const double blocks = std::ceil((double)B / pb);
-        const double per_cu = std::ceil(blocks / h->n_cu);
         const int occ = rvll::loglike_blocks_per_cu(lds);
-        const double resident = std::min(per_cu, (double)occ);
-        const double latency_penalty = resident >= 4 ? 1.0 : resident >= 3 ? 1.03 : resident >= 2 ? 1.10 : 1.5;
-        // workgroups beyond the resident set run in further rounds of `occ` per CU
-        const double cost = per_cu * rounds * latency_penalty;
+        double remaining = std::ceil(blocks / h->n_cu), cost = 0.5 * W;
+        while (remaining > 0) {
+            const double k = std::min((double)occ, remaining);
+            const double pen = k >= 4 ? 1.0 : k >= 3 ? 1.08 : k >= 2 ? 1.25 : 1.6;
+            cost += k * W * pen;
+            remaining -= k;
+        }
         if (cost < best_cost * (1.0 - 1e-9)) { best_cost = cost; best = pb; }
     }
     h->geo_B = B;
