@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--points-per-block", type=int, default=0)
+    ap.add_argument("--precision", default="fp64", choices=["fp64", "mixed", "fp32"],
+                    help="fp64 = the reference's arithmetic (default, the only parity mode)")
     return ap.parse_args()
 
 
@@ -157,7 +159,7 @@ def main():
     if local_rank >= ndev:
         print(f"[rank {rank}] only {ndev} device(s) visible: sharing device {local_rank % ndev} "
               f"(rehearsal only - RCCL refuses two ranks on one GPU and the gloo transport is used)", file=sys.stderr)
-    model = GpuRVModel(w.fixedpardict, w.table, w.parnames, device=local_rank % ndev)
+    model = GpuRVModel(w.fixedpardict, w.table, w.parnames, device=local_rank % ndev, precision=args.precision)
     if args.points_per_block:
         model.set_points_per_block(args.points_per_block)
     model.dev_upload_theta(theta)                # inputs resident in HBM before the timed region
@@ -233,7 +235,9 @@ def main():
             "metric": "live_point_logL_evals_per_sec", "value": value, "unit": "evals/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "vs_baseline": None, "dtype": {"fp64": "f64", "mixed": "f32 Newton / f64 phase+chi2 (NOT a parity mode)",
+                                             "fp32": "f32 / f64 phase+sum (NOT a parity mode)"}[args.precision],
+            "data": "synthetic",
             "config": {"workload": WORKLOAD_TEXT[args.config].format(b=B), "cfg": args.config,
                        "live_points_per_gpu": B, "epochs": w.table.n_epochs, "planets": len(model.layout.planets),
                        "instruments": len(w.table.insts), "free_parameters": w.ndim,

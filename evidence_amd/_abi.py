@@ -23,7 +23,8 @@ K_K1, K_LOGK1 = 0, 1
 P_PERIOD, P_LOGPERIOD = 0, 1
 ECC_DIRECT, ECC_SECOS_SESIN, ECC_ECOS_ESIN = 0, 1, 2
 ANOM_MA0, ANOM_ML0 = 0, 1
-PREC_FP64 = 0
+PREC_FP64, PREC_MIXED, PREC_FP32 = 0, 1, 2
+PRECISIONS = {"fp64": PREC_FP64, "mixed": PREC_MIXED, "fp32": PREC_FP32}
 
 (PRIOR_UNIFORM, PRIOR_JEFFREYS, PRIOR_MODJEFFREYS, PRIOR_UNIFORMFREQUENCY, PRIOR_NORMAL,
  PRIOR_LOGNORMAL, PRIOR_TRUNCRAYLEIGH, PRIOR_TABLE, PRIOR_BETA, PRIOR_GAMMA, PRIOR_ALPHA,

@@ -172,7 +172,8 @@ int validate_layout(const rvll_layout* L)
     if (L->nplanets > 0 && !L->planets) return fail(RVLL_E_INVALID, "planets pointer is null");
     if (!L->insts) return fail(RVLL_E_INVALID, "insts pointer is null");
     if (L->nlinpar > 0 && !L->linpar) return fail(RVLL_E_INVALID, "linpar pointer is null");
-    if (L->precision != RVLL_PREC_FP64) return fail(RVLL_E_UNSUPPORTED, "only fp64 is built");
+    if (L->precision < RVLL_PREC_FP64 || L->precision > RVLL_PREC_FP32)
+        return fail(RVLL_E_INVALID, "unknown precision %d", L->precision);
     if (!(L->tol > 0.) || L->itmax < 1) return fail(RVLL_E_INVALID, "tol/itmax out of range");
     const int D = L->ndim;
     for (int i = 0; i < L->nplanets; ++i) {
@@ -261,7 +262,7 @@ int build_args(rvll_handle* h, const double* d_theta, double* d_logL, int32_t* d
     a.tref_from_data = h->L.tref_from_data;
     for (int i = 0; i < 4; ++i) a.drift[i] = h->L.drift[i];
     a.tref = h->L.tref;
-    a.tol = h->L.tol; a.itmax = h->L.itmax;
+    a.tol = h->L.tol; a.itmax = h->L.itmax; a.precision = h->L.precision;
     a.PB = choose_points_per_block(h, B);
     a.CH = std::min(h->chunk_items, std::max(rvll::kThreads, a.PB * h->Ne));
     a.CH = (a.CH + 1) & ~1;

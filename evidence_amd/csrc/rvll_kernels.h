@@ -36,6 +36,7 @@ struct LoglikeArgs {
     rvll_slot tref;
     double tol;
     int    itmax;
+    int    precision;        // RVLL_PREC_*
     // geometry
     int    PB;               // live points per workgroup
     int    CH;               // contribution slots in LDS (items per chunk)

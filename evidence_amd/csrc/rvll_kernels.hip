@@ -76,6 +76,7 @@ struct ItemCtx {
 };
 
 // One (point, epoch) item: returns ln sqrt(var) + res^2 / (2 var).
+template <int PREC>
 __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx& cx, int pl, int j)
 {
     const double t  = a.t[j];
@@ -100,7 +101,7 @@ __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx&
             double rv;
             if (point_failed && j >= cx.jfail[pl * a.Np + ip]) {
                 rv = p45.x + C0;            // nu left at 0 (rvmodel:488, trueanomaly.c:32-33)
-            } else {
+            } else if constexpr (PREC == RVLL_PREC_FP64) {
                 // mean anomaly, rvmodel:459 — two roundings in (t-epoch), then mul, then add
                 const double M = p01.x * (t - p01.y) + p23.x;
                 // Newton, trueanomaly.c:17-33 — op-by-op, no contraction
@@ -131,6 +132,34 @@ __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx&
                     const double num = __builtin_fma(p45.x, c - ec, -(p45.y * s));
                     rv = div_fast(num, den) + C0;
                 }
+            } else {
+                // reduced precision: phase in fp64 (|M| ~ 1e4 rad, rvmodel:459), reduced to [-pi, pi]
+                // in fp64, then the same Newton rule (start E = M, stop |dE| <= tol, >= 1 step) in fp32
+                const double M = p01.x * (t - p01.y) + p23.x;
+                const float Mf = reduce_2pi_to_f32(M);
+                const float ecf = (float)ec, tolf = (float)a.tol;
+                float E = Mf, s, c, dE;
+                int steps = 0;
+                do {
+                    sincos_f32(E, s, c);
+                    const float f  = E - ecf * s - Mf;
+                    const float fp = 1.0f - ecf * c;
+                    const float En = E - div_f32(f, fp);
+                    dE = En - E;
+                    E = En;
+                    ++steps;
+                } while (fabsf(dE) > tolf && steps < a.itmax);
+                if (steps >= a.itmax) {
+                    atomicMin(&cx.jfail[pl * a.Np + ip], j);
+                    atomicOr(&cx.anyfail[pl], 1);
+                    atomicOr(cx.nfail, 1);
+                    rv = p45.x + C0;
+                } else {
+                    sincos_f32(E, s, c);
+                    const float den = __builtin_fmaf(-ecf, c, 1.0f);
+                    const float num = __builtin_fmaf((float)p45.x, c - ecf, -((float)p45.y * s));
+                    rv = (double)(div_f32(num, den) + (float)C0);
+                }
             }
             ksum += rv;                                                     // rvmodel:383
         }
@@ -147,10 +176,16 @@ __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx&
         rvm += cx.lin[pl * a.nlin + k] * a.linpar[(size_t)k * a.Ne + j];
 
     const double res = y - rvm;                                             // rvmodel:215
-    return 0.5 * log_pos(var) + div_fast(res * res, 2 * var);               // rvmodel:80
+    if constexpr (PREC == RVLL_PREC_FP32) {
+        const float rf = (float)res, vf = (float)var;
+        return (double)(0.5f * __logf(vf) + div_f32(rf * rf, 2.0f * vf));
+    } else {
+        return 0.5 * log_pos(var) + div_fast(res * res, 2 * var);           // rvmodel:80
+    }
 }
 
 // 4 workgroups of 256 per CU (4 waves/SIMD): caps the kernel at 128 VGPRs
+template <int PREC>
 __global__ __launch_bounds__(kThreads, 4)
 void loglike_kernel(const LoglikeArgs a)
 {
@@ -260,7 +295,7 @@ void loglike_kernel(const LoglikeArgs a)
         for (int i = base + tid; i < cend; i += kThreads) {
             const int pl = i / a.Ne;
             const int j  = i - pl * a.Ne;
-            contrib[i - base] = eval_item(a, cx, pl, j);
+            contrib[i - base] = eval_item<PREC>(a, cx, pl, j);
         }
         __syncthreads();
         // 3b. rare: a solve hit itmax.  The reference aborts that planet's array there
@@ -269,7 +304,7 @@ void loglike_kernel(const LoglikeArgs a)
         if (nfail[0] != 0) {
             for (int i = base + tid; i < cend; i += kThreads) {
                 const int pl = i / a.Ne;
-                if (anyfail[pl]) contrib[i - base] = eval_item(a, cx, pl, i - pl * a.Ne);
+                if (anyfail[pl]) contrib[i - base] = eval_item<PREC>(a, cx, pl, i - pl * a.Ne);
             }
             __syncthreads();
         }
@@ -474,7 +509,7 @@ size_t loglike_lds_bytes(const LoglikeArgs& a)
 int loglike_blocks_per_cu(size_t lds_bytes)
 {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, loglike_kernel, kThreads, lds_bytes) != hipSuccess || n < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, loglike_kernel<RVLL_PREC_FP64>, kThreads, lds_bytes) != hipSuccess || n < 1)
         n = 1;
     return n > 8 ? 8 : n;
 }
@@ -484,7 +519,12 @@ hipError_t launch_loglike(const LoglikeArgs& a, hipStream_t stream)
     if (a.B <= 0) return hipSuccess;
     const long long blocks = (a.B + a.PB - 1) / a.PB;
     const size_t lds = loglike_lds_bytes(a);
-    hipLaunchKernelGGL(loglike_kernel, dim3((unsigned)blocks), dim3(kThreads), lds, stream, a);
+    const dim3 grid((unsigned)blocks), block(kThreads);
+    switch (a.precision) {
+    case RVLL_PREC_MIXED: hipLaunchKernelGGL(loglike_kernel<RVLL_PREC_MIXED>, grid, block, lds, stream, a); break;
+    case RVLL_PREC_FP32:  hipLaunchKernelGGL(loglike_kernel<RVLL_PREC_FP32>, grid, block, lds, stream, a); break;
+    default:              hipLaunchKernelGGL(loglike_kernel<RVLL_PREC_FP64>, grid, block, lds, stream, a); break;
+    }
     return hipGetLastError();
 }
 

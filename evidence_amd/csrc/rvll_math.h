@@ -189,6 +189,56 @@ RVLL_HD void rotate_small(double h, double& s, double& c)
     c = c0 + __builtin_fma(c0, ch1, -(s0 * sh));
 }
 
+// ---- fp32 pieces of the reduced-precision modes (RVLL_PREC_MIXED / RVLL_PREC_FP32) ----------
+// sin and cos of a float in roughly [-8, 8] (a mean anomaly already reduced to [-pi, pi] in fp64,
+// plus Newton steps): one Cody-Waite step to [-pi/4, pi/4], degree-7/8 minimax kernels
+// (coefficients: Sun/FreeBSD k_sinf.c, k_cosf.c), ~1 ulp(float).
+RVLL_HD void sincos_f32(float x, float& s_out, float& c_out)
+{
+    const float fk = __builtin_rintf(x * 6.36619772367581382433e-01f);
+    const int q = (int)fk;
+    float r = __builtin_fmaf(-fk, 1.5707963109016418e+00f, x);       // pi/2 high part (24 bits)
+    r = __builtin_fmaf(-fk, 1.5893254773528196e-08f, r);              // pi/2 - high
+    const float z = r * r;
+    float ps = __builtin_fmaf(z, 2.7183114939898219064e-06f, -1.9839334836096632576e-04f);
+    ps = __builtin_fmaf(z, ps, 8.3333293858894631756e-03f);
+    ps = __builtin_fmaf(z, ps, -1.6666666641626524e-01f);
+    const float sr = __builtin_fmaf(r * z, ps, r);
+    float pc = __builtin_fmaf(z, 2.4390448796277409065e-05f, -1.3886763774609929416e-03f);
+    pc = __builtin_fmaf(z, pc, 4.1666623323739063189e-02f);
+    pc = __builtin_fmaf(z, pc, -0.5f);
+    const float cr = __builtin_fmaf(z, pc, 1.0f);
+    const bool swap = (q & 1) != 0;
+    const float s = swap ? cr : sr;
+    const float c = swap ? sr : cr;
+    s_out = (q & 2) ? -s : s;
+    c_out = ((q + 1) & 2) ? -c : c;
+}
+
+// x reduced to [-pi, pi] in fp64 (two-constant Cody-Waite on 2*pi), returned as float.
+RVLL_HD float reduce_2pi_to_f32(double x)
+{
+    constexpr double INV_TWOPI = 1.59154943091895335769e-01;
+    constexpr double TWOPI_HI  = 6.28318530717958623200e+00;
+    constexpr double TWOPI_LO  = 2.44929359829470641435e-16;
+    constexpr double MAGIC     = 6755399441055744.0;
+    const double fk = __builtin_fma(x, INV_TWOPI, MAGIC) - MAGIC;
+    double r = __builtin_fma(-fk, TWOPI_HI, x);
+    r = __builtin_fma(-fk, TWOPI_LO, r);
+    return (float)r;
+}
+
+RVLL_HD float div_f32(float n, float d)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float y = __builtin_amdgcn_rcpf(d);                          // 1 ulp
+    const float q = n * y;
+    return __builtin_fmaf(__builtin_fmaf(-d, q, n), y, q);             // one residual step
+#else
+    return n / d;
+#endif
+}
+
 // counter-based uniform in [0,1): splitmix64 finaliser over (seed, index)
 RVLL_HD double uniform01(uint64_t seed, uint64_t index)
 {

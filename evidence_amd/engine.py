@@ -29,12 +29,14 @@ class GpuRVModel:
     device        HIP device index (default: current device)
     tol, itmax    Newton stop rule of the Kepler solver; defaults 1e-4 and 10000 are what the
                   reference passes (rvmodel/__init__.py:466,491) — change them and parity is gone
+    precision     "fp64" (the reference's arithmetic; the only parity mode), "mixed" (fp64 phase and
+                  chi^2, fp32 Newton iteration) or "fp32" — BASELINE.json configs[4] tolerance sweep
     """
 
     def __init__(self, fixedpardict: Dict[str, float], datadict, parnames: Sequence[str],
                  linpar_dict: Optional[Dict[str, np.ndarray]] = None,
                  priordict: Optional[Dict[str, PriorSpec]] = None, device: int = -1,
-                 tol: Optional[float] = None, itmax: Optional[int] = None):
+                 tol: Optional[float] = None, itmax: Optional[int] = None, precision: str = "fp64"):
         self._lib = _abi.load()          # raises RvllLibraryError when the HIP library is absent
         self._h = _abi.Handle()
         self.fixedpardict = dict(fixedpardict)
@@ -47,6 +49,10 @@ class GpuRVModel:
             self.layout.tol = float(tol)
         if itmax is not None:
             self.layout.itmax = int(itmax)
+        if precision not in _abi.PRECISIONS:
+            raise ValueError(f"precision must be one of {sorted(_abi.PRECISIONS)}")
+        self.precision = precision
+        self.layout.precision = _abi.PRECISIONS[precision]
         self.parnames = list(self.layout.parnames)
         self.nplanets = self.layout.nplanets
         self.drift_in_model = self.layout.has_drift

@@ -73,6 +73,7 @@ class ModelLayout:
     linpar: List[SlotSpec] = field(default_factory=list)
     tol: float = 1.0e-4          # rvmodel/__init__.py:466
     itmax: int = 10000           # rvmodel/__init__.py:491
+    precision: int = _abi.PREC_FP64   # reduced-precision modes are NOT parity modes (include/rvll.h)
 
     @property
     def ndim(self):
@@ -111,7 +112,7 @@ class ModelLayout:
         L.linpar = _abi.C.cast(lin, _abi.C.POINTER(_abi.Slot))
         L.tol = self.tol
         L.itmax = self.itmax
-        L.precision = _abi.PREC_FP64
+        L.precision = int(self.precision)
         return L, (planets, insts, lin)
 
 

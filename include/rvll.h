@@ -103,7 +103,14 @@ typedef struct rvll_inst {
     rvll_slot jitter;   /* {inst}_jitter  (rvmodel:189-190); unused if !has_jitter */
 } rvll_inst;
 
-enum { RVLL_PREC_FP64 = 0 };   /* fp32 / mixed modes are a later-round row */
+/* RVLL_PREC_FP64  : everything fp64, the reference's arithmetic (parity <= 1e-10).
+ * RVLL_PREC_MIXED : mean anomaly and its reduction to [-pi,pi] in fp64 (|M| reaches 1e4 rad, which
+ *                   fp32 cannot hold), Newton iteration + Keplerian in fp32, residual / chi^2 /
+ *                   accumulation in fp64.  NOT parity with the reference: BASELINE.json configs[4]
+ *                   tolerance sweep (~1e-7 relative on log-L).
+ * RVLL_PREC_FP32  : as MIXED, with the per-epoch residual and chi^2 term in fp32 as well (the sum
+ *                   over epochs stays fp64).                                                     */
+enum { RVLL_PREC_FP64 = 0, RVLL_PREC_MIXED = 1, RVLL_PREC_FP32 = 2 };
 
 typedef struct rvll_layout {
     int32_t struct_size;       /* = sizeof(rvll_layout), ABI check            */

@@ -48,6 +48,34 @@ template <int V> __global__ __launch_bounds__(256, 4) void k(double* out, unsign
             sincos(a2, &s, &cc); a2 += s * c + cc; sincos(a3, &s, &cc); a3 += s * c + cc;
         }
     }
+    float f0 = (float)a0, f1 = f0 + 0.1f, f2 = f0 + 0.2f, f3 = f0 + 0.3f, f4 = f0 + 0.4f, f5 = f0 + 0.5f, f6 = f0 + 0.6f, f7 = f0 + 0.7f;
+    const float mf = 0.999999f, cf = 1e-7f;
+    int i0 = threadIdx.x, i1 = i0 + 1, i2 = i0 + 2, i3 = i0 + 3, i4 = i0 + 4, i5 = i0 + 5, i6 = i0 + 6, i7 = i0 + 7;
+    if (V >= 10) for (int i = 0; i < ITER; ++i) {
+        if (V == 10) {      // 8 independent f32 fma
+            f0 = __builtin_fmaf(f0, mf, cf); f1 = __builtin_fmaf(f1, mf, cf); f2 = __builtin_fmaf(f2, mf, cf); f3 = __builtin_fmaf(f3, mf, cf);
+            f4 = __builtin_fmaf(f4, mf, cf); f5 = __builtin_fmaf(f5, mf, cf); f6 = __builtin_fmaf(f6, mf, cf); f7 = __builtin_fmaf(f7, mf, cf);
+        } else if (V == 11) { // 4 sincos_f32
+            float s, cc;
+            rvll::sincos_f32(f0, s, cc); f0 += s * cf + cc; rvll::sincos_f32(f1, s, cc); f1 += s * cf + cc;
+            rvll::sincos_f32(f2, s, cc); f2 += s * cf + cc; rvll::sincos_f32(f3, s, cc); f3 += s * cf + cc;
+        } else if (V == 12) { // 8 div_f32 (+1 add)
+            f0 = rvll::div_f32(cf, f0) + 1.5f; f1 = rvll::div_f32(cf, f1) + 1.5f; f2 = rvll::div_f32(cf, f2) + 1.5f; f3 = rvll::div_f32(cf, f3) + 1.5f;
+            f4 = rvll::div_f32(cf, f4) + 1.5f; f5 = rvll::div_f32(cf, f5) + 1.5f; f6 = rvll::div_f32(cf, f6) + 1.5f; f7 = rvll::div_f32(cf, f7) + 1.5f;
+        } else if (V == 13) { // 8 integer mul-add style ops (v_mad_u32 / v_add / v_xor)
+            i0 = (i0 ^ i1) + 12345; i1 = (i1 ^ i2) + 12345; i2 = (i2 ^ i3) + 12345; i3 = (i3 ^ i4) + 12345;
+            i4 = (i4 ^ i5) + 12345; i5 = (i5 ^ i6) + 12345; i6 = (i6 ^ i7) + 12345; i7 = (i7 ^ i0) + 12345;
+        } else if (V == 14) { // 8 x (cmp f32 + select)
+            f0 = f0 > f1 ? f2 : f3; f1 = f1 > f2 ? f3 : f4; f2 = f2 > f3 ? f4 : f5; f3 = f3 > f4 ? f5 : f6;
+            f4 = f4 > f5 ? f6 : f7; f5 = f5 > f6 ? f7 : f0; f6 = f6 > f7 ? f0 : f1; f7 = f7 > f0 ? f1 : f2;
+        } else if (V == 15) { // 8 cvt f64->f32->f64 round trips
+            a0 = (double)(float)a0 + c; a1 = (double)(float)a1 + c; a2 = (double)(float)a2 + c; a3 = (double)(float)a3 + c;
+            a4 = (double)(float)a4 + c; a5 = (double)(float)a5 + c; a6 = (double)(float)a6 + c; a7 = (double)(float)a7 + c;
+        } else if (V == 16) { // 4 x logf fast
+            f0 = __logf(f0 + 2.f); f1 = __logf(f1 + 2.f); f2 = __logf(f2 + 2.f); f3 = __logf(f3 + 2.f);
+        }
+    }
+    a0 += (double)(f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7) + (double)(i0 + i1 + i2 + i3 + i4 + i5 + i6 + i7);
     unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
     out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
     if (threadIdx.x == 0) { clk[2 * blockIdx.x] = t1 - t0; clk[2 * blockIdx.x + 1] = r1 - r0; }
@@ -87,5 +115,12 @@ int main()
     run<7>("cmp+select f64 x8", 8, out, clk, blocks);
     run<8>("ocml log (+1 add) x4", 4, out, clk, blocks);
     run<9>("ocml sincos (+3 ops) x4", 4, out, clk, blocks);
+    run<10>("f32 fma x8 independent", 8, out, clk, blocks);
+    run<11>("rvll sincos_f32 (+3 ops) x4", 4, out, clk, blocks);
+    run<12>("div_f32 (+1 add) x8", 8, out, clk, blocks);
+    run<13>("int xor+add x8 (2 ops each)", 8, out, clk, blocks);
+    run<14>("cmp+select f32 x8", 8, out, clk, blocks);
+    run<15>("cvt f64->f32->f64 (+1 add) x8", 8, out, clk, blocks);
+    run<16>("__logf (+1 add) x4", 4, out, clk, blocks);
     return 0;
 }

@@ -138,3 +138,27 @@ def test_itmax_abort_semantics_match_oracle(gpu_required):
         assert np.array_equal(flags & 2, rflags & 2), itmax
         assert (flags & 2).any()
         assert golden.rel_err(got, ref).max() <= TOL, (itmax, float(golden.rel_err(got, ref).max()))
+
+
+def test_million_point_batch_and_nonfinite_inputs(gpu_required):
+    """A batch far beyond the BASELINE sizes (10^6 live points, 160 MB of theta): grid sizing, buffer growth
+    and shrink-back; a strided sample is checked against the oracle.  Non-finite theta rows must come back
+    non-finite (NaN) without disturbing their neighbours."""
+    from oracle.oracle import OracleModel
+    w = make_workload(3)
+    n = 1_000_000
+    theta = np.tile(w.sample_theta(50_000, seed=8), (20, 1))
+    theta[12345, 3] = np.nan
+    theta[777_777, 5] = np.inf
+    with GpuRVModel(w.fixedpardict, w.table, w.parnames) as m:
+        got = m.log_likelihood_batch(theta)
+        small = m.log_likelihood_batch(theta[:10])           # capacity stays, smaller batch still right
+        layout = m.layout
+    assert got.shape == (n,) and np.array_equal(small, got[:10])
+    assert np.isnan(got[12345]) and not np.isfinite(got[777_777])
+    assert np.isfinite(got[12344]) and np.isfinite(got[12346])
+    idx = np.arange(0, n, 997)
+    idx = idx[(idx != 12345) & (idx != 777_777)]
+    ref = OracleModel(layout, w.table).loglike(theta[idx], nthreads=8)
+    assert golden.rel_err(got[idx], ref).max() <= TOL
+    assert np.array_equal(got[100_000:150_000], got[150_000:200_000])    # clean tiled copies agree bit for bit

@@ -1,0 +1,50 @@
+"""GPU: the reduced-precision modes (BASELINE.json configs[4]: fp32 vs fp64 tolerance sweep).
+They are NOT parity modes; these tests pin how far they are from the fp64 path and that the fp64
+path is untouched by their existence."""
+import numpy as np
+import pytest
+
+import golden
+from evidence_amd import GpuRVModel
+from evidence_amd.synthetic import make_workload
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(180)]
+
+
+def _run(w, theta, precision):
+    with GpuRVModel(w.fixedpardict, w.table, w.parnames, precision=precision) as m:
+        return m.log_likelihood_batch(theta)
+
+
+@pytest.mark.parametrize("cfg,n", [(2, 4096), (3, 8192), (5, 1024)])
+def test_tolerance_sweep(gpu_required, cfg, n):
+    w = make_workload(cfg)
+    theta = w.sample_theta(n, seed=321 + cfg)
+    ref = _run(w, theta, "fp64")
+    for precision, bound_max, bound_med in (("mixed", 2e-5, 2e-7), ("fp32", 5e-5, 1e-6)):
+        got = _run(w, theta, precision)
+        err = golden.rel_err(got, ref)
+        print(f"cfg{cfg} {precision}: max {err.max():.2e} median {np.median(err):.2e} p99 {np.percentile(err, 99):.2e} "
+              f"max abs {np.max(np.abs(got - ref)):.3e}")
+        assert err.max() <= bound_max and np.median(err) <= bound_med, (cfg, precision, float(err.max()))
+
+
+def test_reduced_precision_keeps_sentinels_and_phase_range(gpu_required):
+    # the invalid-orbit sentinel and the |M| ~ 1e4 rad phase (51Peg: t - epoch ~ 1000 d, P ~ 4 d) survive
+    for case in golden.edge_cases():
+        if case.name == "secos_sesin_invalid":
+            with GpuRVModel(case.fixed, case.table, case.parnames, precision="mixed") as m:
+                assert np.all(m.log_likelihood_batch(case.theta) == -1e30)
+    case = golden.peg51_cases()[0]
+    with GpuRVModel(case.fixed, case.table, case.parnames, precision="mixed") as m:
+        got = m.log_likelihood_batch(case.theta)
+    assert golden.rel_err(got, case.logL).max() <= 2e-5
+
+
+def test_fp64_is_default_and_unchanged(gpu_required):
+    case = golden.config_case(3)
+    with GpuRVModel(case.fixed, case.table, case.parnames) as m:
+        assert m.precision == "fp64"
+        assert golden.rel_err(m.log_likelihood_batch(case.theta), case.logL).max() <= 1e-10
+    with pytest.raises(ValueError):
+        GpuRVModel(case.fixed, case.table, case.parnames, precision="bf16")
