@@ -91,3 +91,21 @@ def test_rccl_allgather_single_rank_and_sharded_wrapper(gpu_required):
             m.allgather_logl(len(case.theta))
         assert np.array_equal(m.download_gathered(len(case.theta)), want)
         m.comm_destroy()
+
+
+def test_reference_style_config_end_to_end(gpu_required):
+    """examples/51peg/config_51peg.py (the reference's config-module format) -> read_config -> GpuRVModel:
+    the BASELINE.md known answers for the shipped 51Peg example come out of the whole chain."""
+    from pathlib import Path
+    from evidence_amd.config import read_config
+    cfg = Path(__file__).resolve().parents[1] / "examples" / "51peg" / "config_51peg.py"
+    rundict, datadict, priordict, fixed = read_config(cfg, nplanets=1)
+    with GpuRVModel(fixed, datadict, list(priordict), priordict=priordict) as m:
+        assert m.parnames == ["hamilton_jitter", "hamilton_offset", "planet1_ecc", "planet1_k1", "planet1_ma0",
+                              "planet1_omega", "planet1_period"] and m.nplanets == 1
+        logl = m.log_likelihood([3.0, -2.0, 0.05, 56.0, 1.0, 0.7, 4.2308])
+        theta = m.prior_transform(np.full(7, 0.37))
+    assert abs(logl - (-11539.57252446112)) <= 1e-10 * 11539.6
+    want = [18.5, -2.5999999999999996, 0.11465599401597197, 1.288249551693134, 2.324778563656447,
+            2.324778563656447, 1.5780337699226765]
+    assert np.max(np.abs(theta - want) / np.abs(want)) <= 1e-13
