@@ -135,6 +135,11 @@ struct rvll_handle {
     bool     gather_pending[2] = {false, false};
     int32_t* d_flags = nullptr;
 
+    // pinned host staging for small transfers (scalar / small-batch callbacks)
+    static constexpr size_t kPinBytes = 1u << 20;
+    void* pin_in = nullptr;
+    void* pin_out = nullptr;
+
     // geometry
     int pb_override = 0;
     long long geo_B = -1;     // batch size the cached geometry was chosen for
@@ -398,6 +403,8 @@ int rvll_create(const rvll_layout* layout, const double* time, const double* vra
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_compute_done, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_gather_done[0], hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_gather_done[1], hipEventDisableTiming));
+    CREATE_TRY(hipHostMalloc(&h->pin_in, rvll_handle::kPinBytes, hipHostMallocDefault));
+    CREATE_TRY(hipHostMalloc(&h->pin_out, rvll_handle::kPinBytes, hipHostMallocDefault));
 
     const size_t nb = sizeof(double) * (size_t)n_epochs;
     std::vector<double> s2((size_t)n_epochs);
@@ -438,6 +445,8 @@ int rvll_destroy(rvll_handle* h)
     dev_free(h->d_theta); dev_free(h->d_cube); dev_free(h->d_logL2[0]); dev_free(h->d_logL2[1]); dev_free(h->d_flags);
     dev_free(h->d_gather);
     for (auto& e : h->ev_gather_done) if (e) (void)hipEventDestroy(e);
+    if (h->pin_in) (void)hipHostFree(h->pin_in);
+    if (h->pin_out) (void)hipHostFree(h->pin_out);
     dev_free(h->d_t); dev_free(h->d_y); dev_free(h->d_s2); dev_free(h->d_inst); dev_free(h->d_linpar);
     dev_free(h->d_planets); dev_free(h->d_insts); dev_free(h->d_linslots);
     if (h->ev_compute_done) (void)hipEventDestroy(h->ev_compute_done);
@@ -524,8 +533,16 @@ int rvll_dev_upload_theta(rvll_handle* h, const double* theta, int64_t B)
     if (rc) return rc;
     if (B == 0) return RVLL_OK;
     if (!theta) return fail(RVLL_E_INVALID, "theta is null");
-    HIP_TRY(hipMemcpyAsync(h->d_theta, theta, sizeof(double) * (size_t)B * (size_t)h->L.ndim,
-                           hipMemcpyHostToDevice, h->compute));
+    const size_t nbytes = sizeof(double) * (size_t)B * (size_t)h->L.ndim;
+    if (nbytes <= rvll_handle::kPinBytes) {
+        // small: stage through pinned memory (a true asynchronous DMA; the caller's buffer is free at once,
+        // and every host-buffer call ends in a stream sync before the staging buffer is written again)
+        HIP_TRY(hipStreamSynchronize(h->compute));
+        memcpy(h->pin_in, theta, nbytes);
+        HIP_TRY(hipMemcpyAsync(h->d_theta, h->pin_in, nbytes, hipMemcpyHostToDevice, h->compute));
+        return RVLL_OK;
+    }
+    HIP_TRY(hipMemcpyAsync(h->d_theta, theta, nbytes, hipMemcpyHostToDevice, h->compute));
     HIP_TRY(hipStreamSynchronize(h->compute));
     return RVLL_OK;
 }
@@ -536,8 +553,16 @@ int rvll_dev_upload_cube(rvll_handle* h, const double* cube, int64_t B)
     if (rc) return rc;
     if (B == 0) return RVLL_OK;
     if (!cube) return fail(RVLL_E_INVALID, "cube is null");
-    HIP_TRY(hipMemcpyAsync(h->d_cube, cube, sizeof(double) * (size_t)B * (size_t)h->L.ndim,
-                           hipMemcpyHostToDevice, h->compute));
+    const size_t nbytes = sizeof(double) * (size_t)B * (size_t)h->L.ndim;
+    if (nbytes <= rvll_handle::kPinBytes) {
+        // small: stage through pinned memory (a true asynchronous DMA; the caller's buffer is free at once,
+        // and every host-buffer call ends in a stream sync before the staging buffer is written again)
+        HIP_TRY(hipStreamSynchronize(h->compute));
+        memcpy(h->pin_in, cube, nbytes);
+        HIP_TRY(hipMemcpyAsync(h->d_cube, h->pin_in, nbytes, hipMemcpyHostToDevice, h->compute));
+        return RVLL_OK;
+    }
+    HIP_TRY(hipMemcpyAsync(h->d_cube, cube, nbytes, hipMemcpyHostToDevice, h->compute));
     HIP_TRY(hipStreamSynchronize(h->compute));
     return RVLL_OK;
 }
@@ -586,9 +611,23 @@ int rvll_dev_download(rvll_handle* h, int64_t B, double* theta, double* logL, in
     if (rc) return rc;
     if (B < 0 || B > h->cap) return fail(RVLL_E_INVALID, "B %lld outside reserved capacity %lld", (long long)B, h->cap);
     if (B > 0) {
-        if (theta) HIP_TRY(hipMemcpyAsync(theta, h->d_theta, sizeof(double) * (size_t)B * (size_t)h->L.ndim, hipMemcpyDeviceToHost, h->compute));
-        if (logL)  HIP_TRY(hipMemcpyAsync(logL, h->d_logL2[h->logl_last], sizeof(double) * (size_t)B, hipMemcpyDeviceToHost, h->compute));
-        if (flags) HIP_TRY(hipMemcpyAsync(flags, h->d_flags, sizeof(int32_t) * (size_t)B, hipMemcpyDeviceToHost, h->compute));
+        const size_t nt = theta ? sizeof(double) * (size_t)B * (size_t)h->L.ndim : 0;
+        const size_t nl = logL ? sizeof(double) * (size_t)B : 0;
+        const size_t nf = flags ? sizeof(int32_t) * (size_t)B : 0;
+        if (nt + nl + nf <= rvll_handle::kPinBytes) {          // small: one pinned landing zone, one sync
+            char* p = static_cast<char*>(h->pin_out);
+            if (nt) HIP_TRY(hipMemcpyAsync(p, h->d_theta, nt, hipMemcpyDeviceToHost, h->compute));
+            if (nl) HIP_TRY(hipMemcpyAsync(p + nt, h->d_logL2[h->logl_last], nl, hipMemcpyDeviceToHost, h->compute));
+            if (nf) HIP_TRY(hipMemcpyAsync(p + nt + nl, h->d_flags, nf, hipMemcpyDeviceToHost, h->compute));
+            HIP_TRY(hipStreamSynchronize(h->compute));
+            if (nt) memcpy(theta, p, nt);
+            if (nl) memcpy(logL, p + nt, nl);
+            if (nf) memcpy(flags, p + nt + nl, nf);
+            return RVLL_OK;
+        }
+        if (theta) HIP_TRY(hipMemcpyAsync(theta, h->d_theta, nt, hipMemcpyDeviceToHost, h->compute));
+        if (logL)  HIP_TRY(hipMemcpyAsync(logL, h->d_logL2[h->logl_last], nl, hipMemcpyDeviceToHost, h->compute));
+        if (flags) HIP_TRY(hipMemcpyAsync(flags, h->d_flags, nf, hipMemcpyDeviceToHost, h->compute));
     }
     HIP_TRY(hipStreamSynchronize(h->compute));
     return RVLL_OK;
