@@ -40,3 +40,47 @@ def test_max_calls_bounds_a_collapsing_run():
     loglike = lambda x: -0.5 * np.sum(((x - 3.3) / 1e-4) ** 2, axis=1)
     res = run_nested(lambda c: -10 + 20 * c, loglike, 3, nlive=50, dlogz=0.01, seed=3, batch=64, max_calls=3000)
     assert res.ncall <= 3000 + 64 and np.isfinite(res.logz)
+
+
+from evidence_amd.nested import run_nested_slice
+
+
+@pytest.mark.parametrize("ndim,nlive", [(1, 200), (2, 400), (6, 400)])
+def test_slice_sampler_gaussian_logz(ndim, nlive):
+    prior = lambda cube: -10.0 + 20.0 * cube
+    loglike = lambda x: -0.5 * np.sum(x * x, axis=1)
+    res = run_nested_slice(prior, loglike, ndim, nlive=nlive, dlogz=0.05, seed=5)
+    want = ndim * LNZ_1D
+    assert abs(res.logz - want) < 0.5                      # tests/test_polychord.py:98,139 tolerance
+    assert abs(res.logz - want) < 4 * res.logzerr + 0.1, (res.logz, want, res.logzerr)
+    w = np.exp(res.logwt)
+    mean = (w[:, None] * res.samples).sum(axis=0)
+    var = (w[:, None] * (res.samples - mean) ** 2).sum(axis=0)
+    assert np.all(np.abs(mean) < 0.35) and np.all(np.abs(var - 1) < 0.4)
+
+
+def test_slice_sampler_bimodal_and_wrapped():
+    # two well-separated modes of equal weight, and a circular parameter whose mode straddles the 0/1 seam
+    def loglike(x):
+        a = -0.5 * np.sum(((x - np.array([-5.0, 0.0])) / 0.5) ** 2, axis=1)
+        b = -0.5 * np.sum(((x - np.array([5.0, 0.0])) / 0.5) ** 2, axis=1)
+        return np.logaddexp(a, b)
+    res = run_nested_slice(lambda c: -10 + 20 * c, loglike, 2, nlive=400, dlogz=0.05, seed=6)
+    want = np.log(2 * 2 * np.pi * 0.25 / 400.0)          # two Gaussians of sigma 0.5 over a 20x20 prior
+    assert abs(res.logz - want) < 0.5
+    w = np.exp(res.logwt)
+    left = w[res.samples[:, 0] < 0].sum()
+    assert 0.3 < left < 0.7                               # both modes kept
+
+    def loglike_circ(x):                                  # von-Mises-like bump centred on the seam of x0
+        return 8.0 * np.cos(2 * np.pi * x[:, 0]) - 0.5 * ((x[:, 1] - 0.5) / 0.1) ** 2
+    r1 = run_nested_slice(lambda c: c, loglike_circ, 2, nlive=300, dlogz=0.05, seed=7, wrapped=[True, False])
+    from scipy.special import i0
+    want = np.log(i0(8.0)) + np.log(np.sqrt(2 * np.pi) * 0.1)
+    assert abs(r1.logz - want) < 0.5
+
+
+def test_slice_sampler_respects_call_budget():
+    res = run_nested_slice(lambda c: -10 + 20 * c, lambda x: -0.5 * np.sum(x * x, axis=1), 3, nlive=100,
+                           dlogz=1e-6, seed=1, max_calls=20000)
+    assert res.ncall < 20000 + 100 * 9 * 200 and np.isfinite(res.logz)
