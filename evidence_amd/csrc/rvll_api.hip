@@ -494,6 +494,18 @@ int rvll_set_priors(rvll_handle* h, const rvll_prior* priors, int32_t ndim)
     free_priors(h);
     std::vector<rvll_prior> dev(priors, priors + ndim);
     for (int d = 0; d < ndim; ++d) {
+        if (dev[d].kind == RVLL_PRIOR_BETA || dev[d].kind == RVLL_PRIOR_GAMMA) {
+            // the device tabulates this prior's quantile function once; the kernel starts from it
+            const size_t nb = sizeof(double) * (size_t)rvll::prior_table_nodes();
+            double *dz0 = nullptr, *dz1 = nullptr;
+            HIP_TRY(hipMalloc(&dz0, nb)); h->d_tables.push_back(dz0);
+            HIP_TRY(hipMalloc(&dz1, nb)); h->d_tables.push_back(dz1);
+            HIP_TRY(rvll::launch_prior_table(dev[d].kind, priors[d].args, dz0, dz1, h->compute));
+            dev[d].table_cdf = dz0;
+            dev[d].table_x = dz1;
+            dev[d].table_n = rvll::prior_table_nodes();
+            continue;
+        }
         if (dev[d].kind != RVLL_PRIOR_TABLE) { dev[d].table_cdf = dev[d].table_x = nullptr; continue; }
         const size_t nb = sizeof(double) * (size_t)dev[d].table_n;
         double *dc = nullptr, *dx = nullptr;
@@ -514,6 +526,7 @@ int rvll_set_priors(rvll_handle* h, const rvll_prior* priors, int32_t ndim)
         HIP_TRY(hipMemcpy(h->d_heavy, heavy.data(), sizeof(int32_t) * heavy.size(), hipMemcpyHostToDevice));
     }
     h->n_heavy = (int)heavy.size();
+    HIP_TRY(hipStreamSynchronize(h->compute));          // start tables are built
     h->have_priors = true;
     return RVLL_OK;
 }

@@ -449,12 +449,28 @@ void prior_heavy_kernel(const PriorArgs a)
         const rvll_prior& pr = a.priors[d];
         const double q = a.cube[b * a.D + d];
         double v;
+        // table_cdf / table_x hold the device-built start table (z, dz/du) of this prior, or null
         if (pr.kind == RVLL_PRIOR_BETA)      // stats.beta.ppf(q, a, b); args[2] = ln B(a,b)
-            v = beta_ppf(q, pr.args[0], pr.args[1], pr.args[2]);
+            v = beta_ppf_table(q, pr.args[0], pr.args[1], pr.args[2], pr.table_cdf, pr.table_x);
         else                                 // stats.gamma.ppf(q, alpha, scale=1/beta); args[2] = ln Gamma(alpha)
-            v = gamma_ppf(q, pr.args[0], pr.args[1], pr.args[2]);
+            v = gamma_ppf_table(q, pr.args[0], pr.args[1], pr.args[2], pr.table_cdf, pr.table_x);
         a.theta[b * a.D + d] = v;
     }
+}
+
+// Tabulate one heavy prior's quantile function in smooth coordinates (rvll_special.h, "tabulated
+// starts"); runs once per rvll_set_priors, one node per thread.
+__global__ __launch_bounds__(kThreads)
+void prior_table_kernel(int kind, double a0, double a1, double a2, double* z, double* dz)
+{
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= kTableN) return;
+    const double u = -kTableU + i * (2. * kTableU / (kTableN - 1));
+    double zi, dzi;
+    if (kind == RVLL_PRIOR_BETA) beta_table_node(a0, a1, a2, u, zi, dzi);
+    else                         gamma_table_node(a0, a2, u, zi, dzi);
+    z[i] = zi;
+    dz[i] = dzi;
 }
 
 __global__ __launch_bounds__(kThreads)
@@ -540,6 +556,15 @@ hipError_t launch_prior(const PriorArgs& a, hipStream_t stream)
     long long hb = (a.B * a.n_heavy + kThreads - 1) / kThreads;
     if (hb > 8192) hb = 8192;
     hipLaunchKernelGGL(prior_heavy_kernel, dim3((unsigned)hb), dim3(kThreads), 0, stream, a);
+    return hipGetLastError();
+}
+
+int prior_table_nodes() { return kTableN; }
+
+hipError_t launch_prior_table(int kind, const double* args, double* z, double* dz, hipStream_t stream)
+{
+    hipLaunchKernelGGL(prior_table_kernel, dim3((kTableN + kThreads - 1) / kThreads), dim3(kThreads), 0, stream,
+                       kind, args[0], args[1], args[2], z, dz);
     return hipGetLastError();
 }
 

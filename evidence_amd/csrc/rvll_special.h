@@ -277,10 +277,135 @@ RVLL_HDF double gammaincinv(double a, double q, double lgam)
     return x;
 }
 
+// ---- tabulated starts ---------------------------------------------------------------------------
+// For a fixed prior the quantile function is tabulated ONCE (on the device, by the solvers above) in
+// coordinates in which it is smooth and asymptotically linear in both tails:
+//     u = logit(q)  ->  z = logit(x)  (Beta)   or   z = ln x  (Gamma),
+// with the analytic slope dz/du = q(1-q) / (x(1-x) pdf(x))  (Beta)  or  q(1-q) / (x pdf(x))  (Gamma).
+// Cubic Hermite interpolation on kTableN nodes over |u| <= kTableU (q in [1e-13, 1-1e-13]) gives a start
+// with relative error ~1e-9; ONE log-space Newton step on the same equation the full solver uses then
+// lands on the solver's answer.  Outside the table, or if that step is not tiny, the full solver runs.
+constexpr int    kTableN = 4096;
+constexpr double kTableU = 30.0;
+
+RVLL_HDF void beta_table_node(double a, double b, double lbeta, double u, double& z, double& dz)
+{
+    if (u <= 0.) {
+        const double q = 1. / (1. + exp(-u));                       // <= 0.5
+        const double x = betaincinv_lowerhalf(a, b, q, lbeta);
+        const BetaEval e = betainc_eval(a, b, x, lbeta);
+        z = log(x) - log1p(-x);
+        dz = q * (1. - q) / (e.xpdf * (1. - x));
+    } else {
+        const double p = 1. / (1. + exp(u));                        // 1 - q, computed without cancellation
+        const double y = betaincinv_lowerhalf(b, a, p, lbeta);      // y = 1 - x
+        const BetaEval e = betainc_eval(b, a, y, lbeta);
+        z = log1p(-y) - log(y);
+        dz = p * (1. - p) / (e.xpdf * (1. - y));
+    }
+}
+
+RVLL_HDF double hermite_table(const double* zt, const double* dzt, double u)
+{
+    const double h = 2. * kTableU / (kTableN - 1);
+    double pos = (u + kTableU) / h;
+    int i = (int)pos;
+    if (i < 0) i = 0;
+    if (i > kTableN - 2) i = kTableN - 2;
+    const double s = pos - i, s2 = s * s, s3 = s2 * s;
+    return (2. * s3 - 3. * s2 + 1.) * zt[i] + (s3 - 2. * s2 + s) * h * dzt[i]
+         + (-2. * s3 + 3. * s2) * zt[i + 1] + (s3 - s2) * h * dzt[i + 1];
+}
+
+// beta_ppf with a tabulated start
+RVLL_HDF double beta_ppf_table(double q, double a, double b, double lbeta, const double* zt, const double* dzt)
+{
+    if (q == 0.) return 0.;
+    if (q == 1.) return 1.;
+    if (!(q > 0. && q < 1.)) return NAN;
+    const double u = log(q) - log1p(-q);
+    if (zt && fabs(u) <= kTableU) {
+        const double z = hermite_table(zt, dzt, u);
+        const bool lower = q <= 0.5;
+        // the solver's variable: x (lower half, target q) or y = 1 - x (upper half, target 1 - q)
+        const double v0 = lower ? 1. / (1. + exp(-z)) : 1. / (1. + exp(z));
+        const double p = lower ? q : 1. - q;
+        const BetaEval e = lower ? betainc_eval(a, b, v0, lbeta) : betainc_eval(b, a, v0, lbeta);
+        const double I = e.direct_is_lower ? e.direct : 1. - e.direct;
+        if (I > 0. && e.xpdf > 0. && fabs(I - p) < 0.5 * p) {
+            const double du = log1p((I - p) / p) * I / e.xpdf;
+            if (fabs(du) <= 1e-6) {
+                const double v = v0 * exp(-du);
+                return lower ? v : 1. - v;
+            }
+        }
+    }
+    return beta_ppf(q, a, b, lbeta);
+}
+
+RVLL_HDF void gamma_table_node(double a, double lgam, double u, double& z, double& dz)
+{
+    const double q = 1. / (1. + exp(-u));
+    const double omq = 1. / (1. + exp(u));
+    // gammaincinv works from q <= 0.5 (P) or 1 - q (Q); give it the exact tail through its own argument form
+    double x;
+    if (u <= 0.) x = gammaincinv(a, q, lgam);
+    else {                                                           // solve Q(a, x) = 1 - q with the exact 1 - q
+        // gammaincinv(a, q) computes 1 - q itself; for u > 0 that loses the tail, so invert through the table's
+        // own equation: bracketed Newton on Q with the exact target
+        double lo = 0., hi = INFINITY;
+        x = gammaincinv(a, q < 1. ? q : 1. - 1e-16, lgam);
+        for (int it = 0; it < 60; ++it) {
+            const GammaEval e = gammainc_eval(a, x, lgam);
+            const double Q = e.direct_is_lower ? 1. - e.direct : e.direct;
+            if (Q < omq) hi = x; else lo = x;
+            double xn = -1.;
+            if (Q > 0. && e.xpdf > 0.) {
+                const double F = (fabs(Q - omq) < 0.5 * omq) ? log1p((Q - omq) / omq) : log(Q / omq);
+                xn = x * exp(F * Q / e.xpdf);
+            }
+            if (!(xn >= lo && xn <= hi) || !(xn > 0.)) xn = (hi < INFINITY) ? 0.5 * (lo + hi) : 2. * x;
+            const double dx = fabs(xn - x);
+            x = xn;
+            if (dx <= 1e-13 * x) break;
+        }
+    }
+    const GammaEval e = gammainc_eval(a, x, lgam);
+    z = log(x);
+    dz = q * omq / e.xpdf;
+}
+
+RVLL_HDF double gammaincinv_table(double a, double q, double lgam, const double* zt, const double* dzt)
+{
+    if (q == 0.) return 0.;
+    if (q == 1.) return INFINITY;
+    if (!(q > 0. && q < 1.)) return NAN;
+    const double u = log(q) - log1p(-q);
+    if (zt && fabs(u) <= kTableU) {
+        const double x0 = exp(hermite_table(zt, dzt, u));
+        const bool lower = q <= 0.5;
+        const double p = lower ? q : 1. - q;
+        const GammaEval e = gammainc_eval(a, x0, lgam);
+        const double P = e.direct_is_lower ? e.direct : 1. - e.direct;
+        const double Q = e.direct_is_lower ? 1. - e.direct : e.direct;
+        const double val = lower ? P : Q;
+        if (val > 0. && e.xpdf > 0. && fabs(val - p) < 0.5 * p) {
+            const double F = log1p((val - p) / p);
+            const double du = lower ? F * val / e.xpdf : -F * val / e.xpdf;
+            if (fabs(du) <= 1e-6) return x0 * exp(-du);
+        }
+    }
+    return gammaincinv(a, q, lgam);
+}
+
 // scipy.stats.gamma.ppf(q, alpha, scale = 1/beta) (evidence/priors.py:424-425)
 RVLL_HDF double gamma_ppf(double q, double alpha, double beta, double lgam)
 {
     return gammaincinv(alpha, q, lgam) * (1.0 / beta);
+}
+RVLL_HDF double gamma_ppf_table(double q, double alpha, double beta, double lgam, const double* zt, const double* dzt)
+{
+    return gammaincinv_table(alpha, q, lgam, zt, dzt) * (1.0 / beta);
 }
 
 // scipy.stats.alpha.ppf(q, a) = 1 / (a - ndtri(q * Phi(a)))   (Phi(a) precomputed on the host)
