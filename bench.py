@@ -46,8 +46,8 @@ WORKLOAD_TEXT = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="live points per GPU (default: the config's)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -84,6 +84,16 @@ def host_cpu_share():
     return n
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(w, layout, theta, gpu_logl, seconds):
     """The oracle (C restatement of the reference path) on this node's host cores, OpenMP over live
     points, on a bounded sample of the same workload.  Reported baseline, not the target."""
@@ -108,7 +118,7 @@ def cpu_baseline(w, layout, theta, gpu_logl, seconds):
         "value": done / el, "unit": "evals/s", "cores": threads, "kind": "port",
         "sample": f"{done} evaluations ({done // n} passes over the same {n}-point batch, {el:.1f} s)",
         "single_thread_evals_per_s": one,
-        "host_logical_cpus": os.cpu_count(),
+        "host_logical_cpus": os.cpu_count(), "cpu_model": cpu_model(),
     }, float(err.max()), float(iters.mean())
 
 
@@ -245,7 +255,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.config, B),
                          "kernel": "loglike_kernel", "kernel_ms_mean": tm["kernel_ms_mean"],
-                         "kernel_ms_min": tm["kernel_ms_min"], "algorithmic_bytes_per_launch": abytes,
+                         "kernel_ms_min": tm["kernel_ms_min"], "kernel_ms_median": tm["kernel_ms_median"],
+                         "algorithmic_bytes_per_launch": abytes,
                          "points_per_block": tm["points_per_block"], "blocks": tm["blocks"],
                          "kernel_evals_per_s": B / kern_s,
                          "note": "fused kernel is fp64-VALU bound, not HBM bound (DESIGN.md); see valu_fp64"},
@@ -277,7 +288,8 @@ def main():
             out["roofline"]["valu_fp64"] = {"achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
                                             "frac": tf / FP64_VALU_PEAK_TFLOPS, "flops_per_eval": f_eval,
                                             "mean_newton_steps": mean_it,
-                                            "kepler_solves_per_s": B / kern_s * len(model.layout.planets) * w.table.n_epochs}
+                                            "kepler_solves_per_s": B / kern_s * len(model.layout.planets) * w.table.n_epochs,
+                                            "newton_iterations_per_s": B / kern_s * len(model.layout.planets) * w.table.n_epochs * mean_it}
         print(json.dumps(out), flush=True)
 
     if gather == "rccl":
