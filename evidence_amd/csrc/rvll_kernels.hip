@@ -500,6 +500,8 @@ void debug_eval_kernel(int op, const double* x, const double* y, long long n, do
         case 7: r = ndtri_f64(a); break;
         case 8: sincos_f64(a, s, c); rotate_small(b, s, c); r = s; break;
         case 9: sincos_f64(a, s, c); rotate_small(b, s, c); r = c; break;
+        case 10: r = div_1nr(a, b); break;
+        case 11: r = __builtin_amdgcn_rcp(a); break;
         default: r = NAN; break;
         }
         out[i] = r;

@@ -95,22 +95,39 @@ RVLL_HD void sincos_f64(double x, double& s_out, double& c_out)
     double sr, cr;
     sincos_kernel(r, sr, cr);
 
-    // quadrant: q&1 swaps, bit 1 of q flips sin, bit 1 of (q+1) flips cos
-    const bool swap = (q & 1u) != 0u;
-    const double s = swap ? cr : sr;
-    const double c = swap ? sr : cr;
-    const uint64_t ssign = (uint64_t)(q & 2u) << 62;
-    const uint64_t csign = (uint64_t)((q + 1u) & 2u) << 62;
-    s_out = as_double(as_u64(s) ^ ssign);
-    c_out = as_double(as_u64(c) ^ csign);
+    // quadrant: q&1 swaps, bit 1 of q flips sin, bit 1 of (q+1) flips cos.  Done with bit selects
+    // (v_bfi_b32 / v_xor_b32, ~2 cycles each) rather than compare + v_cndmask (~4 cycles each, measured).
+    const uint32_t m = 0u - (q & 1u);                              // all ones when the quadrant swaps
+    const uint64_t sb = as_u64(sr), cb = as_u64(cr);
+    const uint32_t s_lo = (uint32_t)sb, s_hi = (uint32_t)(sb >> 32);
+    const uint32_t c_lo = (uint32_t)cb, c_hi = (uint32_t)(cb >> 32);
+    uint32_t rs_lo, rs_hi, rc_lo, rc_hi;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // v_bfi_b32 D, M, A, B = (M & A) | (~M & B): one instruction per 32-bit half (hipcc expands the C form
+    // below into twice as many and/or operations)
+    asm("v_bfi_b32 %0, %4, %7, %5\n\t"
+        "v_bfi_b32 %1, %4, %8, %6\n\t"
+        "v_bfi_b32 %2, %4, %5, %7\n\t"
+        "v_bfi_b32 %3, %4, %6, %8"
+        : "=&v"(rs_lo), "=&v"(rs_hi), "=&v"(rc_lo), "=&v"(rc_hi)
+        : "v"(m), "v"(s_lo), "v"(s_hi), "v"(c_lo), "v"(c_hi));
+#else
+    rs_lo = (c_lo & m) | (s_lo & ~m);
+    rs_hi = (c_hi & m) | (s_hi & ~m);
+    rc_lo = (s_lo & m) | (c_lo & ~m);
+    rc_hi = (s_hi & m) | (c_hi & ~m);
+#endif
+    rs_hi ^= (q & 2u) << 30;
+    rc_hi ^= ((q + 1u) & 2u) << 30;
+    s_out = as_double(((uint64_t)rs_hi << 32) | rs_lo);
+    c_out = as_double(((uint64_t)rc_hi << 32) | rc_lo);
 }
 
-// n / d by reciprocal refinement.  div_exact is the sequence hipcc itself emits for an
-// IEEE fp64 division (v_rcp_f64, two Newton steps, quotient, one residual correction) minus
-// v_div_scale / v_div_fmas / v_div_fixup, which only act when an exponent is near the ends
-// of the range: for finite, normal operands with a normal quotient it returns the correctly
-// rounded quotient, bit for bit what `n / d` gives (tests/test_gpu_math.py).  div_fast drops
-// the residual step (<= ~2 ulp), for quotients that do not feed the Newton stop rule.
+// n / d by reciprocal refinement.  v_rcp_f64 is accurate to 2^-24.4 (measured, scripts/rcp_probe.py): one
+// Newton step gives 2^-48, and the quotient with one residual correction q + (n - d q) y is then the
+// correctly rounded quotient for finite, normal operands with a normal quotient — bit for bit what `n / d`
+// (hipcc: v_div_scale, v_rcp, two Newton steps, v_div_fmas, v_div_fixup; 58 cycles) returns, on 8e6 + 4e6
+// operand pairs of the solver's range (tests/test_gpu_math.py), in 38 cycles.
 RVLL_HD double recip_refined(double d)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -123,25 +140,19 @@ RVLL_HD double recip_refined(double d)
     return 1.0 / d;
 #endif
 }
-RVLL_HD double div_exact(double n, double d)
+RVLL_HD double div_1nr(double n, double d)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const double y = recip_refined(d);
+    double y = __builtin_amdgcn_rcp(d);
+    y = __builtin_fma(y, __builtin_fma(-d, y, 1.0), y);
     const double q = n * y;
-    const double r = __builtin_fma(-d, q, n);
-    return __builtin_fma(r, y, q);
+    return __builtin_fma(__builtin_fma(-d, q, n), y, q);
 #else
     return n / d;
 #endif
 }
-RVLL_HD double div_fast(double n, double d)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return n * recip_refined(d);
-#else
-    return n / d;
-#endif
-}
+RVLL_HD double div_exact(double n, double d) { return div_1nr(n, d); }
+RVLL_HD double div_fast(double n, double d) { return div_1nr(n, d); }
 
 // Natural log of a finite positive double: argument split by v_frexp, f = m - 1 with
 // m in [sqrt(1/2), sqrt(2)), s = f/(2+f), and the degree-14 even minimax in s (coefficients:
@@ -175,14 +186,14 @@ RVLL_HD double log_pos(double v)
 #endif
 }
 
-// Rotate (s, c) = (sin E0, cos E0) to E0 + h for a small step |h| <= ~1e-3:
-// sin h and cos h by short Taylor sums (h^7/5040 < 2e-25 at 1e-3).
+// Rotate (s, c) = (sin E0, cos E0) to E0 + h for a small step |h| <= 1e-3:
+// sin h = h (1 - h^2/6), cos h - 1 = h^2 (-1/2 + h^2/24); the neglected terms are h^5/120 <= 8.4e-18 and
+// h^6/720 <= 1.4e-21 at the bound (the Newton stop rule gives |h| <= 1e-4: 8e-23).
 RVLL_HD void rotate_small(double h, double& s, double& c)
 {
     const double h2 = h * h;
-    // sin h = h (1 - h2/6 + h2^2/120),  cos h = 1 - h2/2 + h2^2/24 - h2^3/720
-    const double sh = h * __builtin_fma(h2, __builtin_fma(h2, 8.33333333333333333333e-03, -1.66666666666666666667e-01), 1.0);
-    const double ch1 = h2 * __builtin_fma(h2, __builtin_fma(h2, -1.38888888888888888889e-03, 4.16666666666666666667e-02), -0.5);
+    const double sh = h * __builtin_fma(h2, -1.66666666666666666667e-01, 1.0);
+    const double ch1 = h2 * __builtin_fma(h2, 4.16666666666666666667e-02, -0.5);
     // s' = s cos h + c sin h = s + (s*ch1 + c*sh);  c' = c + (c*ch1 - s*sh)
     const double s0 = s, c0 = c;
     s = s0 + __builtin_fma(s0, ch1, c0 * sh);
