@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--config", type=int, default=3, choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=0, help="live points per GPU (default: the config's)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-extras", action="store_true", help="skip the host-roundtrip / prior+loglike extras (profiling)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--points-per-block", type=int, default=0)
     ap.add_argument("--precision", default="fp64", choices=["fp64", "mixed", "fp32"],
@@ -261,7 +262,7 @@ def main():
                          "kernel_evals_per_s": B / kern_s,
                          "note": "fused kernel is fp64-VALU bound, not HBM bound (DESIGN.md); see valu_fp64"},
         }
-        if world == 1:
+        if world == 1 and not args.no_extras:
             # extras (never `value`): PCIe-inclusive host round trip, and cube -> theta -> log-L all on device
             model.log_likelihood_batch(theta)
             t1 = time.perf_counter()

@@ -9,8 +9,9 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --steps 50 --warmup 5 --no-cpu"
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $BENCH > $OUT/stats.log 2>&1
+BENCH="python3 $R/bench.py --steps 50 --warmup 5 --no-cpu --no-extras"
+STEADY="python3 $R/bench.py --no-cpu --no-extras"      # the default 2000-step run, for the duration that must agree with bench.py
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $STEADY > $OUT/stats.log 2>&1
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU --output-format csv -d $OUT/pmcA -- $BENCH > $OUT/pmcA.log 2>&1
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmcB -- $BENCH > $OUT/pmcB.log 2>&1
 timeout -k 10 200 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmcC -- $BENCH > $OUT/pmcC.log 2>&1
@@ -19,4 +20,5 @@ cd $R
 cat $OUT/stats/*/*_kernel_stats.csv > $OUT/kernel_stats.csv
 python3 scripts/pmc_summary.py "$OUT/pmc*/*/*_counter_collection.csv" > $OUT/pmc_summary.txt
 cat $OUT/kernel_stats.csv
+grep -h "^{" $OUT/stats.log | tail -1 > $OUT/bench_under_profiler.json || true
 cat $OUT/pmc_summary.txt
