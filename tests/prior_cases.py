@@ -25,10 +25,16 @@ def comparable_mask(name, q, raised):
     return m
 
 
-def rel_err(got, ref):
+def abs_scale(name, args):
+    """Where the reference's own formula subtracts two nearly equal numbers the meaningful error is relative
+    to the subtrahend, not to the tiny result: ModJeffreys is x0 (1 + xmax/x0)^q - x0 (priors.py:82-83)."""
+    return float(args[0]) if name == "ModJeffreys" else 0.0
+
+
+def rel_err(got, ref, scale=0.0):
     got, ref = np.asarray(got, float), np.asarray(ref, float)
     with np.errstate(all="ignore"):
-        e = np.abs(got - ref) / np.maximum(np.abs(ref), 1e-300)
+        e = np.abs(got - ref) / np.maximum(np.maximum(np.abs(ref), scale), 1e-300)
     e = np.where(got == ref, 0.0, e)
     e = np.where(np.isnan(got) & np.isnan(ref), 0.0, e)
     # near a zero crossing (Normal(0,1) at q = 0.5, Uniform(-10,10) ...) use an absolute floor

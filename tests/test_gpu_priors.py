@@ -24,7 +24,7 @@ def test_device_ppf_matches_reference(gpu_required, name, args, vals, raised):
     with one_param_model(pc.spec_for(name, args)) as m:
         got = m.prior_transform_batch(Q.reshape(-1, 1))[:, 0]
     mask = pc.comparable_mask(name, Q, raised)
-    err = pc.rel_err(got[mask], vals[mask])
+    err = pc.rel_err(got[mask], vals[mask], pc.abs_scale(name, args))
     assert err.max() <= pc.TOL.get(name, pc.DEFAULT_TOL), (name, args, float(err.max()), float(Q[mask][err.argmax()]))
     assert np.all(np.isnan(got[raised]))            # where the reference raises ValueError we return NaN
 
@@ -94,3 +94,37 @@ def test_sorted_uniform_forced_identifiability(gpu_required):
     want = 1.0 + 99.0 * t
     assert pc.rel_err(got[:, idx], want).max() <= 1e-14
     assert np.all(np.diff(got[:, idx], axis=1) >= 0)          # sorted: that is the point of the prior
+
+
+@pytest.mark.parametrize("name,args,vals,raised", SETS, ids=[f"{n}{tuple(a)}" for n, a, _, _ in SETS])
+def test_device_ppf_matches_oracle_on_dense_random_q(gpu_required, name, args, vals, raised):
+    """Beyond the 64-point golden grid: 30 000 random unit-cube coordinates per distribution against the
+    numpy/scipy oracle (itself pinned by the golden vectors, tests/test_priors_oracle.py)."""
+    from oracle import priors_oracle as po
+    rng = np.random.default_rng(hash(name) % 1000)
+    q = np.concatenate([rng.random(28_000), 10.0 ** rng.uniform(-9, -1, 1000), 1 - 10.0 ** rng.uniform(-9, -1, 1000)])
+    with one_param_model(pc.spec_for(name, args)) as m:
+        got = m.prior_transform_batch(q.reshape(-1, 1))[:, 0]
+    ref = po.ppf(name, args, q)
+    mask = pc.comparable_mask(name, q, np.isnan(ref))
+    err = pc.rel_err(got[mask], ref[mask], pc.abs_scale(name, args))
+    assert err.max() <= pc.TOL.get(name, pc.DEFAULT_TOL), (name, args, float(err.max()), float(q[mask][err.argmax()]))
+    assert np.all(np.isnan(got[np.isnan(ref)]))
+
+
+def test_sorted_loguniform_against_oracle(gpu_required):
+    from oracle import priors_oracle as po
+    table = EpochTable.from_arrays(["ia"], [50000.0, 50001.0], [1.0, -1.0], [1.0, 1.0], [0, 0])
+    names = ["planet1_period", "planet2_period", "ia_offset"]
+    fixed = {}
+    for n in (1, 2):
+        fixed.update({f"planet{n}_k1": 1.0, f"planet{n}_ecc": 0.0, f"planet{n}_omega": 0.0, f"planet{n}_ma0": 0.0,
+                      f"planet{n}_epoch": 0.0})
+    pri = {"planet1_period": P.SortedLogUniform(1.5, 1000.0), "planet2_period": P.SortedLogUniform(1.5, 1000.0),
+           "ia_offset": P.Uniform(-1, 1)}
+    cube = np.random.default_rng(1).random((2000, 3))
+    with GpuRVModel(fixed, table, names, priordict=pri) as m:
+        idx = [m.parnames.index("planet1_period"), m.parnames.index("planet2_period")]
+        got = m.prior_transform_batch(cube)
+    want = po.sorted_uniform(cube[:, idx], 1.5, 1000.0, log=True)
+    assert pc.rel_err(got[:, idx], want).max() <= 1e-13
