@@ -83,3 +83,54 @@ class ShardedLogLike:
         parts = [torch.empty(pad, dtype=torch.float64) for _ in range(self.world)]
         dist.all_gather(parts, mine)
         return unpad(torch.cat(parts).numpy(), n, self.world)
+
+
+class MultiDeviceLogLike:
+    """One process, several GPUs: the same contiguous live-point shards, one GpuRVModel (handle) per device,
+    one host thread per device (the ctypes calls release the GIL, so uploads, kernels and downloads of the
+    devices overlap).  For samplers that run in a single process (UltraNest without MPI, nested.py): no
+    launcher, no communicator — the per-shard log-L come back through each device's own PCIe link and are
+    concatenated on the host.  The process-per-GPU + RCCL form above is what bench.py scales with."""
+
+    def __init__(self, models):
+        from concurrent.futures import ThreadPoolExecutor
+        if not models:
+            raise ValueError("at least one model")
+        self.models = list(models)
+        self._pool = ThreadPoolExecutor(max_workers=len(self.models))
+
+    @classmethod
+    def create(cls, fixedpardict, datadict, parnames, devices, **kwargs):
+        from .engine import GpuRVModel
+        return cls([GpuRVModel(fixedpardict, datadict, parnames, device=d, **kwargs) for d in devices])
+
+    @property
+    def parnames(self):
+        return self.models[0].parnames
+
+    def log_likelihood_batch(self, theta):
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        bounds = partition(theta.shape[0], len(self.models))
+        futures = [self._pool.submit(m.log_likelihood_batch, theta[lo:hi]) if hi > lo else None
+                   for m, (lo, hi) in zip(self.models, bounds)]
+        parts = [f.result() if f is not None else np.empty(0) for f in futures]
+        return np.concatenate(parts) if parts else np.empty(0)
+
+    def prior_loglike_batch(self, cubes):
+        cubes = np.ascontiguousarray(cubes, dtype=np.float64)
+        bounds = partition(cubes.shape[0], len(self.models))
+        futures = [self._pool.submit(m.prior_loglike_batch, cubes[lo:hi]) if hi > lo else None
+                   for m, (lo, hi) in zip(self.models, bounds)]
+        res = [f.result() for f in futures if f is not None]
+        return np.concatenate([r[0] for r in res]), np.concatenate([r[1] for r in res])
+
+    def close(self):
+        self._pool.shutdown(wait=True)
+        for m in self.models:
+            m.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

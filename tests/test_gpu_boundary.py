@@ -137,3 +137,20 @@ def test_51peg_evidence_run_is_gpu_fed_and_reproducible(gpu_required):
     ip, ik = m.parnames.index("planet1_period"), m.parnames.index("planet1_k1")
     assert abs(np.sum(w * a.samples[:, ip]) - 4.2308) < 0.01
     assert abs(np.sum(w * a.samples[:, ik]) - 56.0) < 6.0
+
+
+def test_single_process_multi_handle_sharding(gpu_required):
+    """MultiDeviceLogLike with two handles (both on device 0 here; on a node: one per GPU): same values, same
+    order as one handle, for even and ragged batch sizes and for the fused prior+log-L call."""
+    from evidence_amd.sharded import MultiDeviceLogLike
+    w = make_workload(3)
+    pri = w.priordict()
+    with GpuRVModel(w.fixedpardict, w.table, w.parnames, priordict=pri) as one, \
+            MultiDeviceLogLike.create(w.fixedpardict, w.table, w.parnames, devices=[0, 0, 0], priordict=pri) as multi:
+        for n in (3000, 3001, 2, 1):
+            theta = w.sample_theta(n, seed=n)
+            assert np.array_equal(multi.log_likelihood_batch(theta), one.log_likelihood_batch(theta))
+        cube = w.sample_cube(1000, 5)
+        t1, l1 = one.prior_loglike_batch(cube)
+        t2, l2 = multi.prior_loglike_batch(cube)
+        assert np.array_equal(t1, t2) and np.array_equal(l1, l2)
