@@ -106,6 +106,7 @@ PROTOTYPES = {
     "rvll_allgather_logl": (C.c_int, [Handle, C.c_int64]),
     "rvll_download_gathered": (C.c_int, [Handle, C.c_int64, _dp]),
     "rvll_comm_destroy": (C.c_int, [Handle]),
+    "rvll_kep_rv_batch": (C.c_int, [Handle, _dp, C.c_int64, _dp, C.c_int32, C.c_uint32, _dp]),
     "rvll_debug_eval": (C.c_int, [Handle, C.c_int32, _dp, _dp, C.c_int64, _dp]),
     "rvll_last_error": (C.c_char_p, []),
     "rvll_version": (C.c_int, [_ip, _ip]),

@@ -747,6 +747,36 @@ int rvll_prior_loglike_batch(rvll_handle* h, const double* cube, int64_t B,
     return rvll_dev_download(h, B, theta_out, logL, flags);
 }
 
+// ---- Keplerian curves (post-processing helper) ------------------------------------------------------
+int rvll_kep_rv_batch(rvll_handle* h, const double* theta, int64_t B, const double* times, int32_t n_times,
+                      uint32_t include_mask, double* out)
+{
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (B < 0 || n_times < 0) return fail(RVLL_E_INVALID, "negative size");
+    if (B == 0 || n_times == 0) return RVLL_OK;
+    if (!theta || !times || !out) return fail(RVLL_E_INVALID, "null buffer");
+    rc = rvll_dev_upload_theta(h, theta, B);
+    if (rc) return rc;
+    double *d_times = nullptr, *d_out = nullptr;
+    int status = RVLL_OK;
+    hipError_t e = hipMalloc(&d_times, sizeof(double) * (size_t)n_times);
+    if (e == hipSuccess) e = hipMalloc(&d_out, sizeof(double) * (size_t)B * (size_t)n_times);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_times, times, sizeof(double) * (size_t)n_times, hipMemcpyHostToDevice, h->compute);
+    if (e == hipSuccess) {
+        rvll::LoglikeArgs a;
+        status = build_args(h, h->d_theta, h->d_logL2[h->logl_cur], h->d_flags, B, &a);
+        if (status == RVLL_OK) e = rvll::launch_keprv(a, d_times, n_times, include_mask, d_out, h->compute);
+    }
+    if (status == RVLL_OK && e == hipSuccess)
+        e = hipMemcpyAsync(out, d_out, sizeof(double) * (size_t)B * (size_t)n_times, hipMemcpyDeviceToHost, h->compute);
+    if (status == RVLL_OK && e == hipSuccess) e = hipStreamSynchronize(h->compute);
+    if (status == RVLL_OK && e != hipSuccess) status = fail(RVLL_E_HIP, "kep_rv_batch: %s", hipGetErrorString(e));
+    (void)hipStreamSynchronize(h->compute);
+    dev_free(d_times); dev_free(d_out);
+    return status;
+}
+
 // ---- diagnostics ---------------------------------------------------------------------
 int rvll_debug_eval(rvll_handle* h, int32_t op, const double* x, const double* y, int64_t n, double* out)
 {

@@ -62,6 +62,8 @@ hipError_t launch_prior(const PriorArgs& a, hipStream_t stream);
 int prior_table_nodes();
 hipError_t launch_prior_table(int kind, const double* args, double* z, double* dz, hipStream_t stream);
 
+hipError_t launch_keprv(const LoglikeArgs& a, const double* times, int Nt, unsigned include_mask, double* out,
+                        hipStream_t stream);
 hipError_t launch_debug_eval(int op, const double* x, const double* y, long long n, double* out, hipStream_t stream);
 hipError_t launch_fill_cube(double* cube, long long n, uint64_t seed, hipStream_t stream);
 

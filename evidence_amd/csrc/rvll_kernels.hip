@@ -481,6 +481,63 @@ void fill_cube_kernel(double* cube, long long n, uint64_t seed)
         cube[i] = uniform01(seed, (uint64_t)i);
 }
 
+// Keplerian curves at arbitrary times: kep_rv(pardict, time, exclude_planet) and modelk(pardict, time, planet)
+// of evidence/rvmodel/__init__.py:343-463 for a batch of parameter vectors, as post_processing.py:413-428 uses
+// them for phase folds.  One thread per (live point, time); planets selected by a bit mask.  Not a hot path:
+// every thread decodes its planets itself.  An invalid orbit (the reference returns None) gives NaN.
+__global__ __launch_bounds__(kThreads)
+void keprv_kernel(const LoglikeArgs a, const double* times, int Nt, unsigned include_mask, double* out)
+{
+    const long long n = a.B * (long long)Nt;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads) {
+        const long long b = i / Nt;
+        const double t = times[(int)(i - b * Nt)];
+        const double* th = a.theta + b * a.D;
+        double sum = 0.;
+        bool valid = true;
+        for (int ip = 0; ip < a.Np; ++ip) {
+            if (!((include_mask >> ip) & 1u)) continue;
+            const rvll_planet& d = a.planets[ip];
+            const double kraw = slot_get(d.k, th), praw = slot_get(d.p, th);
+            const double K = d.k_kind == RVLL_K_LOGK1 ? exp(kraw) : kraw;
+            const double Pd = d.p_kind == RVLL_P_LOGPERIOD ? exp(praw) : praw;
+            const double e1 = slot_get(d.e1, th), e2 = slot_get(d.e2, th);
+            double ecc, omega;
+            if (d.ecc_kind == RVLL_ECC_SECOS_SESIN) { ecc = e1 * e1 + e2 * e2; omega = atan2(e2, e1); if (ecc > 1) valid = false; }
+            else if (d.ecc_kind == RVLL_ECC_ECOS_ESIN) { ecc = sqrt(e1 * e1 + e2 * e2); omega = atan2(e2, e1); if (ecc > 1) valid = false; }
+            else { ecc = e1; omega = e2; }
+            const double anom = slot_get(d.anom, th);
+            const double ma0 = d.anom_kind == RVLL_ANOM_ML0 ? anom - omega : anom;
+            const double ec = ecc > 0.99 ? 0.99 : ecc;
+            const double M = (kTwoPi / Pd) * (t - slot_get(d.epoch, th)) + ma0;
+            double E = M, s, c, dE;
+            int steps = 0;
+            do {
+                sincos_f64(E, s, c);
+                const double f = E - ec * s - M;
+                const double fp = 1 - ec * c;
+                const double En = E - div_exact(f, fp);
+                dE = En - E;
+                E = En;
+                ++steps;
+            } while (fabs(dE) > a.tol && steps < a.itmax);
+            double so, co;
+            sincos_f64(omega, so, co);
+            double rv;
+            if (steps >= a.itmax) {
+                rv = K * (co + ecc * co);     // a single time has no "rest of the array": nu stays 0 for this element
+            } else {
+                sincos_f64(E, s, c);
+                const double q = sqrt((1. - ec) * (1. + ec));
+                const double den = __builtin_fma(-ec, c, 1.0);
+                rv = K * (div_exact((c - ec) * co - q * s * so, den) + ecc * co);
+            }
+            sum += rv;
+        }
+        out[i] = valid ? sum : NAN;
+    }
+}
+
 // device-math self test (rvll_debug_eval): out[i] = op(x[i], y[i])
 __global__ __launch_bounds__(kThreads)
 void debug_eval_kernel(int op, const double* x, const double* y, long long n, double* out)
@@ -516,6 +573,17 @@ hipError_t launch_debug_eval(int op, const double* x, const double* y, long long
     long long blocks = (n + kThreads - 1) / kThreads;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(debug_eval_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, op, x, y, n, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_keprv(const LoglikeArgs& a, const double* times, int Nt, unsigned include_mask, double* out,
+                        hipStream_t stream)
+{
+    const long long n = a.B * (long long)Nt;
+    if (n <= 0) return hipSuccess;
+    long long blocks = (n + kThreads - 1) / kThreads;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(keprv_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, a, times, Nt, include_mask, out);
     return hipGetLastError();
 }
 

@@ -134,6 +134,31 @@ class GpuRVModel:
         x = np.asarray(x, dtype=np.float64).reshape(1, -1)
         return float(self.log_likelihood_batch(x)[0])
 
+    # ---- Keplerian curves for post-processing -----------------------------------------------------
+    def _curves(self, X, time, mask):
+        X = self._theta2d(np.atleast_2d(np.asarray(X, dtype=np.float64)))
+        time = np.ascontiguousarray(np.atleast_1d(time), dtype=np.float64)
+        out = np.empty((X.shape[0], time.shape[0]), dtype=np.float64)
+        _abi.check(self._lib.rvll_kep_rv_batch(self._h, _abi.as_dp(X), X.shape[0], _abi.as_dp(time), time.shape[0],
+                                               int(mask), _abi.as_dp(out)))
+        return out
+
+    def kep_rv_batch(self, X, time, exclude_planet=None):
+        """RVModel.kep_rv for every row of X: the summed Keplerian RV of all planets except
+        `exclude_planet` (1-based, as rvmodel/__init__.py:343-385) at `time` -> [n, len(time)]."""
+        if not (exclude_planet is None or type(exclude_planet) is int):
+            raise AssertionError(f"exclude_planet has to be an {int}, got {type(exclude_planet)}.")   # rvmodel:365-366
+        mask = (1 << self.nplanets) - 1
+        if exclude_planet is not None and 1 <= exclude_planet <= self.nplanets:
+            mask &= ~(1 << (exclude_planet - 1))
+        return self._curves(X, time, mask)
+
+    def modelk_batch(self, X, time, planet):
+        """RVModel.modelk for every row of X: the Keplerian curve of one planet (1-based, rvmodel:388-463)."""
+        if not 1 <= int(planet) <= self.nplanets:
+            raise KeyError(f"planet{planet}_k1")
+        return self._curves(X, time, 1 << (int(planet) - 1))
+
     # ---- prior transform --------------------------------------------------------------------
     def prior_transform_batch(self, cubes):
         cubes = self._theta2d(cubes)

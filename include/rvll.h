@@ -242,6 +242,15 @@ int rvll_allgather_logl(rvll_handle* h, int64_t B_local);
 int rvll_download_gathered(rvll_handle* h, int64_t B_total, double* logL_all);
 int rvll_comm_destroy(rvll_handle* h);
 
+/* ---- Keplerian curves at arbitrary times (post-processing helper) ------------------ */
+/* Replaces RVModel.kep_rv(pardict, time, exclude_planet) and RVModel.modelk(pardict, time, planet)
+ * (evidence/rvmodel/__init__.py:343-385, 388-463) as evidence/post_processing.py:413-428 calls them for
+ * phase folds: out[b][j] = sum over planets ip with bit ip of include_mask set of the Keplerian RV of
+ * theta[b] at times[j].  kep_rv(exclude_planet=k) is mask = all bits but k-1; modelk(planet=k) is
+ * mask = 1 << (k-1).  An invalid orbit (the reference returns None) gives a NaN row.                  */
+int rvll_kep_rv_batch(rvll_handle* h, const double* theta, int64_t B, const double* times,
+                      int32_t n_times, uint32_t include_mask, double* out /*[B, n_times]*/);
+
 /* ---- diagnostics -------------------------------------------------------------- */
 /* Evaluate one device math routine elementwise (tests only; no reference counterpart):
  * op 0 sin, 1 cos (rvll sincos), 2 div_exact(x,y), 3 x/y (IEEE), 4 div_fast(x,y),

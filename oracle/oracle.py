@@ -43,6 +43,8 @@ def load():
         lib.rvo_iteration_counts.restype = C.c_int
         lib.rvo_iteration_counts.argtypes = [C.POINTER(_abi.Layout), _dp, C.c_int, _dp, _ip]
         lib.rvo_max_threads.restype = C.c_int
+        lib.rvo_kep_rv_batch.restype = C.c_int
+        lib.rvo_kep_rv_batch.argtypes = [C.POINTER(_abi.Layout), _dp, C.c_long, _dp, C.c_int, C.c_uint, _dp]
         _lib = lib
     return _lib
 
@@ -102,6 +104,16 @@ class OracleModel:
         if rc != 0:
             raise MemoryError("oracle allocation failed")
         return (out, flags) if return_flags else out
+
+    def kep_rv(self, theta, times, include_mask):
+        theta = np.ascontiguousarray(np.atleast_2d(theta), dtype=np.float64)
+        times = np.ascontiguousarray(times, dtype=np.float64)
+        out = np.empty((theta.shape[0], times.shape[0]))
+        rc = self.lib.rvo_kep_rv_batch(C.byref(self._c), _abi.as_dp(theta), theta.shape[0], _abi.as_dp(times),
+                                       times.shape[0], int(include_mask), _abi.as_dp(out))
+        if rc != 0:
+            raise MemoryError("oracle allocation failed")
+        return out
 
     def iteration_counts(self, theta):
         theta = np.ascontiguousarray(theta, dtype=np.float64).reshape(-1)

@@ -277,6 +277,37 @@ RVO_EXPORT int rvo_iteration_counts(const rvll_layout* L, const double* time, in
     return 0;
 }
 
+/* Keplerian curves at arbitrary times, restating evidence/rvmodel/__init__.py:343-385 (kep_rv with
+ * exclude_planet) and :388-463 (modelk): planet ip contributes iff bit ip of include_mask is set.
+ * out: [B][Nt].  An invalid orbit (the reference returns None, :430-431,438-439,380) gives a NaN row.      */
+RVO_EXPORT int rvo_kep_rv_batch(const rvll_layout* L, const double* theta, long B, const double* times, int Nt,
+                                unsigned include_mask, double* out)
+{
+    double* ma = (double*)malloc(sizeof(double) * 2 * (size_t)(Nt > 0 ? Nt : 1));
+    if (!ma) return -1;
+    double* nu = ma + Nt;
+    for (long b = 0; b < B; ++b) {
+        const double* th = theta + (size_t)b * L->ndim;
+        double* row = out + (size_t)b * Nt;
+        int valid = 1;
+        for (int j = 0; j < Nt; ++j) row[j] = 0.;
+        for (int ip = 0; ip < L->nplanets && valid; ++ip) {
+            if (!((include_mask >> ip) & 1u)) continue;
+            planet_pars q = planet_decode(&L->planets[ip], th);
+            if (!q.valid) { valid = 0; break; }
+            const double w = 2 * M_PI / q.P;
+            for (int j = 0; j < Nt; ++j) ma[j] = w * (times[j] - q.epoch) + q.ma0;
+            memset(nu, 0, sizeof(double) * (size_t)Nt);
+            rvo_trueanomaly(ma, Nt, q.ecc, nu, L->itmax, L->tol, NULL);
+            const double ecw = q.ecc * cos(q.omega);
+            for (int j = 0; j < Nt; ++j) row[j] += q.K * (cos(nu[j] + q.omega) + ecw);
+        }
+        if (!valid) for (int j = 0; j < Nt; ++j) row[j] = NAN;
+    }
+    free(ma);
+    return 0;
+}
+
 RVO_EXPORT int rvo_max_threads(void)
 {
 #ifdef _OPENMP

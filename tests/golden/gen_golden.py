@@ -8,6 +8,7 @@ writes small fixtures (inputs + expected outputs) next to this file:
     loglike_edges.npz/.json parametrisation and edge cases
     loglike_51peg.npz/.json the shipped 51Peg example, both configs
     priors.npz/.json        .ppf of every working distribution on a q grid (§8c.4)
+    keprv.npz/.json         kep_rv(exclude_planet) / modelk(planet) curves at arbitrary times (§8f.3)
 
 The reference never travels to the GPU box; these fixtures do.  Dev-only shim:
 `numpy.int = int` (evidence/rvmodel/__init__.py:53 uses the alias numpy removed).
@@ -317,9 +318,37 @@ def gen_priors():
     print("51Peg prior(0.37):", [float(getattr(ref_priors, n)(*a).ppf(0.37)) for _, n, a in cfg])
 
 
+def gen_keprv():
+    """kep_rv(exclude_planet) and modelk(planet) curves (evidence/rvmodel/__init__.py:343-463) at times that
+    are NOT the data epochs, as post_processing.py:413-428 calls them."""
+    arrays, meta = {}, []
+    for cfg, n in ((3, 6), (2, 4)):
+        w = make_workload(cfg)
+        theta = w.sample_theta(n, seed=7000 + cfg)
+        times = np.linspace(49990.0, 52010.0, 57)
+        model = RVModel(dict(w.fixedpardict), ref_datadict(w.table), list(w.parnames))
+        npl = model.nplanets
+        curves = {}
+        for k in range(n):
+            pardict = {name: theta[k, i] for i, name in enumerate(model.parnames)}
+            pardict.update(model.fixedpardict)
+            for ex in [None] + list(range(1, npl + 1)):
+                curves.setdefault(f"ex{ex}", []).append(model.kep_rv(pardict, times, exclude_planet=ex))
+            for pl in range(1, npl + 1):
+                curves.setdefault(f"pl{pl}", []).append(model.modelk(pardict, times, planet=pl))
+        arrays[f"cfg{cfg}_theta"], arrays[f"cfg{cfg}_times"] = theta, times
+        for key, rows in curves.items():
+            arrays[f"cfg{cfg}_{key}"] = np.array(rows)
+        meta.append(dict(cfg=cfg, nplanets=npl, keys=sorted(curves)))
+        print(f"keprv cfg{cfg}: {n} points x {len(times)} times, {len(curves)} curve kinds")
+    np.savez_compressed(HERE / "keprv.npz", **arrays)
+    (HERE / "keprv.json").write_text(json.dumps(meta, indent=1))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["configs", "edges", "51peg", "priors"]
+    which = sys.argv[1:] or ["configs", "edges", "51peg", "priors", "keprv"]
     if "configs" in which: gen_configs()
     if "edges" in which: gen_edges()
     if "51peg" in which: gen_51peg()
     if "priors" in which: gen_priors()
+    if "keprv" in which: gen_keprv()

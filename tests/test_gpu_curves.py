@@ -1,0 +1,47 @@
+"""GPU: batched kep_rv(exclude_planet) / modelk(planet) curves against the golden curves produced by the
+reference itself (tests/golden/keprv.npz) and the oracle."""
+import json
+
+import numpy as np
+import pytest
+
+import golden
+from evidence_amd import GpuRVModel
+from evidence_amd.synthetic import make_workload
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(180)]
+Z = np.load(golden.GOLDEN / "keprv.npz")
+META = json.loads((golden.GOLDEN / "keprv.json").read_text())
+
+
+@pytest.mark.parametrize("meta", META, ids=[f"cfg{m['cfg']}" for m in META])
+def test_curves_match_reference(gpu_required, meta):
+    cfg = meta["cfg"]
+    w = make_workload(cfg)
+    theta, times = Z[f"cfg{cfg}_theta"], Z[f"cfg{cfg}_times"]
+    with GpuRVModel(w.fixedpardict, w.table, w.parnames) as m:
+        for key in meta["keys"]:
+            ref = Z[f"cfg{cfg}_{key}"]
+            if key.startswith("ex"):
+                ex = None if key == "exNone" else int(key[2:])
+                got = m.kep_rv_batch(theta, times, exclude_planet=ex)
+            else:
+                got = m.modelk_batch(theta, times, planet=int(key[2:]))
+            assert got.shape == ref.shape
+            assert np.max(np.abs(got - ref)) <= 1e-11 * max(1.0, np.abs(ref).max()), key
+        with pytest.raises(AssertionError):
+            m.kep_rv_batch(theta, times, exclude_planet=1.0)          # rvmodel:365-366
+
+
+def test_curves_match_oracle_at_scale_and_invalid_orbit_is_nan(gpu_required):
+    from oracle.oracle import OracleModel
+    w = make_workload(3)
+    theta = w.sample_theta(300, seed=3)
+    times = np.linspace(50000.0, 52000.0, 1001)
+    with GpuRVModel(w.fixedpardict, w.table, w.parnames) as m:
+        got = m.kep_rv_batch(theta, times, exclude_planet=2)
+        ref = OracleModel(m.layout, w.table).kep_rv(theta, times, 0b101)
+    assert np.max(np.abs(got - ref)) <= 1e-11 * np.abs(ref).max()
+    case = [c for c in golden.edge_cases() if c.name == "secos_sesin_invalid"][0]
+    with GpuRVModel(case.fixed, case.table, case.parnames) as m:
+        assert np.all(np.isnan(m.kep_rv_batch(case.theta, case.table.time)))
