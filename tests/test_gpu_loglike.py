@@ -186,3 +186,60 @@ def test_no_step_count_flips_in_a_quarter_billion_solves(gpu_required):
     assert calm.mean() > 0.97
     assert err[calm].max() <= 1e-13, float(err[calm].max())
     assert np.percentile(err, 99.99) <= 1e-14
+
+
+def _synthetic_case(rng, n_epochs, nplanets, ninst, drift=False, nlin=0, nfree_only_offset=False):
+    """A model of arbitrary shape with every planet/instrument parameter free (or only one offset free)."""
+    from evidence_amd.data import EpochTable
+    t = np.sort(rng.uniform(50000.0, 53000.0, n_epochs))
+    inst = rng.integers(0, ninst, n_epochs)
+    inst[:ninst] = np.arange(ninst)
+    order = np.argsort(inst, kind="stable")
+    names_i = [f"i{k}" for k in range(ninst)]
+    table = EpochTable.from_arrays(names_i, t[order], rng.normal(0, 10, n_epochs), rng.uniform(0.5, 3, n_epochs),
+                                   inst[order].astype(np.int32))
+    free, fixed, ranges = [], {}, {}
+    for p in range(1, nplanets + 1):
+        for suf, lo, hi in (("k1", 0.5, 30), ("period", 2, 300), ("ecc", 0, 0.8), ("omega", 0, 6.28), ("ma0", 0, 6.28)):
+            free.append(f"planet{p}_{suf}"); ranges[free[-1]] = (lo, hi)
+        fixed[f"planet{p}_epoch"] = 51000.0 + p
+    for nm in names_i:
+        free += [f"{nm}_offset", f"{nm}_jitter"]
+        ranges[f"{nm}_offset"], ranges[f"{nm}_jitter"] = (-5, 5), (0, 5)
+    if drift:
+        free += ["drift_lin", "drift_quad"]; ranges["drift_lin"] = ranges["drift_quad"] = (-2, 2)
+        fixed["drift_tref"] = 51500.0
+    linpar = {}
+    for k in range(nlin):
+        free.append(f"linpar_s{k}"); ranges[free[-1]] = (-2, 2)
+        linpar[f"s{k}"] = rng.normal(0, 1, n_epochs)
+    if nfree_only_offset:
+        keep = f"{names_i[0]}_offset"
+        for nm in free:
+            if nm != keep:
+                fixed[nm] = 0.5 * sum(ranges[nm])
+        free = [keep]
+    return table, sorted(free), fixed, ranges, linpar
+
+
+@pytest.mark.parametrize("n_epochs,nplanets,ninst,drift,nlin,only_offset,npts", [
+    (10_000, 1, 2, False, 0, False, 96),      # one live point spans three 4096-slot LDS windows
+    (5_000, 2, 1, True, 0, False, 64),        # ... with drift, two planets
+    (1, 1, 1, False, 0, False, 300),          # a single epoch
+    (63, 8, 5, True, 3, False, 257),          # many planets / instruments / linear terms, ragged batch
+    (200, 2, 2, False, 0, True, 1000),        # exactly one free parameter, everything else fixed
+])
+def test_unusual_model_shapes_match_oracle(gpu_required, n_epochs, nplanets, ninst, drift, nlin, only_offset, npts):
+    from oracle.oracle import OracleModel
+    rng = np.random.default_rng(n_epochs * 31 + nplanets)
+    table, free, fixed, ranges, linpar = _synthetic_case(rng, n_epochs, nplanets, ninst, drift, nlin, only_offset)
+    theta = np.stack([rng.uniform(*ranges[nm], npts) for nm in free], axis=1)
+    with GpuRVModel(fixed, table, free, linpar_dict=linpar or None) as m:
+        got = m.log_likelihood_batch(theta)
+        layout = m.layout
+        for pb in (1, 2, 7):
+            m.set_points_per_block(pb)
+            assert golden.rel_err(m.log_likelihood_batch(theta), got).max() <= 1e-13
+    series = np.stack([linpar[k] for k in layout.linpar_names]) if layout.linpar_names else None
+    ref = OracleModel(layout, table, series).loglike(theta, nthreads=8)
+    assert golden.rel_err(got, ref).max() <= TOL, float(golden.rel_err(got, ref).max())
