@@ -145,8 +145,12 @@ def _chord(u, d, wrapped):
 
 def run_nested_slice(prior: Callable, loglike: Callable, ndim: int, nlive: int = 400, kbatch: Optional[int] = None,
                      nsteps: Optional[int] = None, dlogz: float = 0.5, max_iter: int = 10_000_000,
-                     max_calls: int = 50_000_000, wrapped=None, seed: int = 0) -> NestedResult:
+                     max_calls: int = 50_000_000, wrapped=None, seed: int = 0,
+                     prior_loglike: Optional[Callable] = None) -> NestedResult:
     """Nested sampling with `kbatch` deaths per iteration and batched hit-and-run slice sampling.
+
+    `prior_loglike(cubes) -> (theta, logl)`, if given, replaces the prior + loglike pair inside the loop
+    (GpuRVModel.prior_loglike_batch: one upload, two launches, one download per round).
 
     Each iteration removes the `kbatch` lowest live points in order (the live count shrinks nlive,
     nlive-1, ... while they die, as in dynamic nested sampling), then draws `kbatch` replacements above
@@ -203,8 +207,11 @@ def run_nested_slice(prior: Callable, loglike: Callable, ndim: int, nlive: int =
                 if wrapped is not None:
                     cand[:, wrapped] %= 1.0
                 cand = np.clip(cand, 0.0, np.nextafter(1.0, 0.0))
-                ct = np.asarray(prior(cand), dtype=np.float64)
-                cl = np.asarray(loglike(ct), dtype=np.float64)          # one batch = one GPU launch
+                if prior_loglike is not None:
+                    ct, cl = prior_loglike(cand)                        # one round trip to the GPU
+                else:
+                    ct = np.asarray(prior(cand), dtype=np.float64)
+                    cl = np.asarray(loglike(ct), dtype=np.float64)      # one batch = one GPU launch
                 ncall += todo.size
                 ok = cl > lstar
                 acc = todo[ok]

@@ -24,6 +24,7 @@ try:
 except ImportError:
     from evidence_amd.nested import run_nested_slice
     res = run_nested_slice(prior, loglike, model.ndim, nlive=400, dlogz=0.5, max_calls=20_000_000,
-                           wrapped=wrapped_params(model.parnames), seed=int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+                           wrapped=wrapped_params(model.parnames), seed=int(sys.argv[1]) if len(sys.argv) > 1 else 0,
+                           prior_loglike=model.prior_loglike_batch)
     print(f"{rundict['target']}: ln Z = {res.logz:.3f} +- {res.logzerr:.3f} "
           f"({res.niter} iterations, {res.ncall} likelihood calls)")

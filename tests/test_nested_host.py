@@ -84,3 +84,12 @@ def test_slice_sampler_respects_call_budget():
     res = run_nested_slice(lambda c: -10 + 20 * c, lambda x: -0.5 * np.sum(x * x, axis=1), 3, nlive=100,
                            dlogz=1e-6, seed=1, max_calls=20000)
     assert res.ncall < 20000 + 100 * 9 * 200 and np.isfinite(res.logz)
+
+
+def test_fused_callback_gives_the_same_run():
+    prior = lambda c: -10.0 + 20.0 * c
+    loglike = lambda x: -0.5 * np.sum(x * x, axis=1)
+    a = run_nested_slice(prior, loglike, 3, nlive=100, dlogz=0.5, seed=9)
+    b = run_nested_slice(prior, loglike, 3, nlive=100, dlogz=0.5, seed=9,
+                         prior_loglike=lambda c: (prior(c), loglike(prior(c))))
+    assert a.logz == b.logz and a.ncall == b.ncall
