@@ -399,7 +399,13 @@ int rvll_create(const rvll_layout* layout, const double* time, const double* vra
     CREATE_TRY(hipGetDeviceProperties(&prop, device));
     h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     CREATE_TRY(hipStreamCreateWithFlags(&h->compute, hipStreamNonBlocking));
-    CREATE_TRY(hipStreamCreateWithFlags(&h->comm, hipStreamNonBlocking));
+    {
+        // the all-gather is a tiny kernel that must not queue behind the next saturating log-L launch:
+        // highest priority for the comm stream (numerically lowest value)
+        int prio_least = 0, prio_greatest = 0;
+        CREATE_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+        CREATE_TRY(hipStreamCreateWithPriority(&h->comm, hipStreamNonBlocking, prio_greatest));
+    }
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_compute_done, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_gather_done[0], hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_gather_done[1], hipEventDisableTiming));
