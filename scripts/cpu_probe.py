@@ -1,6 +1,5 @@
 import os, sys, time
 sys.path.insert(0, os.getcwd())
-import numpy as np
 print("cpu_count", os.cpu_count(), "affinity", len(os.sched_getaffinity(0)))
 for f in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us"):
     try: print(f, open(f).read().strip())

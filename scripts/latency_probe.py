@@ -2,7 +2,6 @@
 """Wall-clock latency of the host-buffer calls a sampler makes, by batch size (run on the GPU box)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 from evidence_amd import GpuRVModel
 from evidence_amd.synthetic import make_workload
 

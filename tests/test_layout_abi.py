@@ -4,7 +4,6 @@ import ctypes as C
 import re
 from pathlib import Path
 
-import numpy as np
 import pytest
 
 from evidence_amd import _abi
