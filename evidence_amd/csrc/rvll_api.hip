@@ -139,6 +139,8 @@ struct rvll_handle {
     static constexpr size_t kPinBytes = 1u << 20;
     void* pin_in = nullptr;
     void* pin_out = nullptr;
+    void* pin_in_dev = nullptr;      // device-visible aliases of the two pinned buffers (zero-copy path)
+    void* pin_out_dev = nullptr;
 
     // geometry
     int pb_override = 0;
@@ -409,8 +411,10 @@ int rvll_create(const rvll_layout* layout, const double* time, const double* vra
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_compute_done, hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_gather_done[0], hipEventDisableTiming));
     CREATE_TRY(hipEventCreateWithFlags(&h->ev_gather_done[1], hipEventDisableTiming));
-    CREATE_TRY(hipHostMalloc(&h->pin_in, rvll_handle::kPinBytes, hipHostMallocDefault));
-    CREATE_TRY(hipHostMalloc(&h->pin_out, rvll_handle::kPinBytes, hipHostMallocDefault));
+    CREATE_TRY(hipHostMalloc(&h->pin_in, rvll_handle::kPinBytes, hipHostMallocMapped));
+    CREATE_TRY(hipHostMalloc(&h->pin_out, rvll_handle::kPinBytes, hipHostMallocMapped));
+    CREATE_TRY(hipHostGetDevicePointer(&h->pin_in_dev, h->pin_in, 0));
+    CREATE_TRY(hipHostGetDevicePointer(&h->pin_out_dev, h->pin_out, 0));
 
     const size_t nb = sizeof(double) * (size_t)n_epochs;
     std::vector<double> s2((size_t)n_epochs);
@@ -717,6 +721,26 @@ int rvll_loglike_batch(rvll_handle* h, const double* theta, int64_t B, double* l
     if (B < 0) return fail(RVLL_E_INVALID, "B < 0");
     if (B == 0) return use_device(h);
     if (!theta || !logL) return fail(RVLL_E_INVALID, "theta/logL is null");
+    const size_t nin = sizeof(double) * (size_t)B * (size_t)h->L.ndim;
+    const size_t nout = (sizeof(double) + sizeof(int32_t)) * (size_t)B;
+    if (nin <= 64 * 1024 && nout <= 64 * 1024) {
+        // scalar / small-batch callback: zero-copy.  The kernel reads theta straight from mapped pinned host
+        // memory and writes log-L and flags back into it — no copy commands, one launch, one sync.
+        int rc = use_device(h);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(h->compute));
+        memcpy(h->pin_in, theta, nin);
+        double* out_l = static_cast<double*>(h->pin_out_dev);
+        int32_t* out_f = reinterpret_cast<int32_t*>(out_l + B);
+        rvll::LoglikeArgs a;
+        rc = build_args(h, static_cast<const double*>(h->pin_in_dev), out_l, out_f, B, &a);
+        if (rc) return rc;
+        HIP_TRY(rvll::launch_loglike(a, h->compute));
+        HIP_TRY(hipStreamSynchronize(h->compute));
+        memcpy(logL, h->pin_out, sizeof(double) * (size_t)B);
+        if (flags) memcpy(flags, static_cast<char*>(h->pin_out) + sizeof(double) * (size_t)B, sizeof(int32_t) * (size_t)B);
+        return RVLL_OK;
+    }
     int rc = rvll_dev_upload_theta(h, theta, B);
     if (rc) return rc;
     rc = rvll_dev_loglike(h, B);
