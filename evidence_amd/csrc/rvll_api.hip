@@ -768,6 +768,33 @@ int rvll_prior_loglike_batch(rvll_handle* h, const double* cube, int64_t B,
     if (h && !h->have_priors) return fail(RVLL_E_NOPRIORS, "rvll_set_priors has not been called");
     if (B == 0) return use_device(h);
     if (!cube || !logL) return fail(RVLL_E_INVALID, "cube/logL is null");
+    const size_t nin = sizeof(double) * (size_t)B * (size_t)h->L.ndim;
+    const size_t nout = (sizeof(double) + sizeof(int32_t)) * (size_t)B;
+    if (nin <= 64 * 1024 && nout <= 64 * 1024) {
+        // small batch (a sampler's proposal round): the prior kernels read the cube from mapped pinned host
+        // memory, theta stays in HBM for the log-L kernel, log-L and flags are written back zero-copy; theta
+        // returns with one copy command into the same pinned block
+        int rc = rvll_dev_reserve(h, B);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(h->compute));
+        memcpy(h->pin_in, cube, nin);
+        rvll::PriorArgs pa{static_cast<const double*>(h->pin_in_dev), h->d_theta, (long long)B, h->L.ndim,
+                           h->d_priors, h->d_heavy, h->n_heavy};
+        HIP_TRY(rvll::launch_prior(pa, h->compute));
+        double* out_l = static_cast<double*>(h->pin_out_dev);
+        int32_t* out_f = reinterpret_cast<int32_t*>(out_l + B);
+        rvll::LoglikeArgs a;
+        rc = build_args(h, h->d_theta, out_l, out_f, B, &a);
+        if (rc) return rc;
+        HIP_TRY(rvll::launch_loglike(a, h->compute));
+        char* host_out = static_cast<char*>(h->pin_out);
+        if (theta_out) HIP_TRY(hipMemcpyAsync(host_out + nout, h->d_theta, nin, hipMemcpyDeviceToHost, h->compute));
+        HIP_TRY(hipStreamSynchronize(h->compute));
+        memcpy(logL, host_out, sizeof(double) * (size_t)B);
+        if (flags) memcpy(flags, host_out + sizeof(double) * (size_t)B, sizeof(int32_t) * (size_t)B);
+        if (theta_out) memcpy(theta_out, host_out + nout, nin);
+        return RVLL_OK;
+    }
     int rc = rvll_dev_upload_cube(h, cube, B);
     if (rc) return rc;
     rc = rvll_dev_prior(h, B);
