@@ -123,6 +123,26 @@ def cpu_baseline(w, layout, theta, gpu_logl, seconds):
     }, float(err.max()), float(iters.mean())
 
 
+def call_with_timeout(fn, seconds):
+    """Run fn() in a daemon thread (the ctypes calls release the GIL) and give up after `seconds`: a stuck RCCL
+    bootstrap must not hang the whole scaling run.  Returns (value, error)."""
+    import threading
+    box = {}
+
+    def run():
+        try:
+            box["value"] = fn()
+        except Exception as exc:                      # noqa: BLE001 - handed back to the caller
+            box["error"] = exc
+
+    t = threading.Thread(target=run, daemon=True)
+    t.start()
+    t.join(seconds)
+    if t.is_alive():
+        return None, TimeoutError(f"no answer after {seconds:.0f} s")
+    return box.get("value"), box.get("error")
+
+
 def device_count():
     import ctypes
     from evidence_amd import _abi
@@ -182,19 +202,20 @@ def main():
         # store carries it.  Every rank reports whether its init worked; if ANY failed, all ranks fall
         # back to gathering the downloaded log-L over gloo (a slower TRANSPORT, same kernel), so the run
         # still completes and says so in `config.allgather`.
-        ok = 1
-        try:
-            ids = [GpuRVModel.comm_unique_id() if rank == 0 else None]
-        except Exception as exc:                       # noqa: BLE001 - reported below
-            ids, ok = [None], 0
-            print(f"[rank {rank}] RCCL unavailable: {exc}", file=sys.stderr)
+        ok, stuck = 1, False
+        ids = [None]
+        if rank == 0:
+            uid, err = call_with_timeout(GpuRVModel.comm_unique_id, 120.0)
+            if err is not None:
+                ok, stuck = 0, isinstance(err, TimeoutError)
+                print(f"[rank {rank}] RCCL unavailable: {err}", file=sys.stderr)
+            ids = [uid]
         dist.broadcast_object_list(ids, src=0)
         if ok and ids[0] is not None:
-            try:
-                model.comm_init(ids[0], world, rank)
-            except Exception as exc:                   # noqa: BLE001
-                ok = 0
-                print(f"[rank {rank}] rvll_comm_init failed: {exc}", file=sys.stderr)
+            _, err = call_with_timeout(lambda: model.comm_init(ids[0], world, rank), 180.0)
+            if err is not None:
+                ok, stuck = 0, stuck or isinstance(err, TimeoutError)
+                print(f"[rank {rank}] rvll_comm_init failed: {err}", file=sys.stderr)
         else:
             ok = 0
         flag = torch.tensor([ok], dtype=torch.int32)
@@ -274,6 +295,18 @@ def main():
             for _ in range(10):
                 model.log_likelihood_batch(theta)
             out["host_roundtrip_evals_per_s"] = 10 * B / (time.perf_counter() - t1)
+            # two launches in flight on alternating pipeline lanes (how the N > 1 step overlaps its all-gather):
+            # independent batches hide each other's ramp-up and tail
+            for _ in range(100):
+                model.dev_loglike(B); model.dev_flip_lane()
+            model.dev_sync()
+            t1 = time.perf_counter()
+            for _ in range(1000):
+                model.dev_loglike(B); model.dev_flip_lane()
+            model.dev_sync()
+            out["two_lane_pipelined_evals_per_s"] = 1000 * B / (time.perf_counter() - t1)
+            if model.dev_flip_lane() != 0:
+                model.dev_flip_lane()
             model.set_priors(w.priordict())
             model.dev_fill_cube(B, seed=99)
             for _ in range(5):
@@ -300,9 +333,13 @@ def main():
 
     if gather == "rccl":
         model.comm_destroy()
-    model.close()
     if dist:
         dist.barrier()
+    if world > 1 and stuck:
+        sys.stdout.flush()
+        os._exit(0)          # a thread is still blocked inside the RCCL bootstrap: do not wait for it
+    model.close()
+    if dist:
         dist.destroy_process_group()
 
 

@@ -53,6 +53,7 @@ struct Rccl {
     int (*CommInitRank)(void**, int, Id128, int) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
+    int (*CommSplit)(void*, int, int, void**, void*) = nullptr;     // optional (second pipeline lane)
     const char* (*GetErrorString)(int) = nullptr;
 };
 constexpr int kNcclFloat64 = 8;   // ncclDouble / ncclFloat64 in rccl.h
@@ -72,6 +73,7 @@ int rccl_load()
     r.CommInitRank   = (int (*)(void**, int, Id128, int))dlsym(lib, "ncclCommInitRank");
     r.AllGather      = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(lib, "ncclAllGather");
     r.CommDestroy    = (int (*)(void*))dlsym(lib, "ncclCommDestroy");
+    r.CommSplit      = (int (*)(void*, int, int, void**, void*))dlsym(lib, "ncclCommSplit");
     r.GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
     if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy || !r.GetErrorString) {
         dlclose(lib);
@@ -95,9 +97,8 @@ void dev_free(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
 
 struct rvll_handle {
     int device = 0;
-    hipStream_t compute = nullptr;
-    hipStream_t comm = nullptr;
-    hipEvent_t  ev_compute_done = nullptr;
+    hipStream_t compute = nullptr;          // lane 0: every single-GPU call runs here
+    hipStream_t lane1 = nullptr;            // lane 1: the second pipeline lane of the multi-GPU step (see rvll_allgather_logl)
 
     // layout (host mirror, then device copies)
     rvll_layout L{};
@@ -128,12 +129,11 @@ struct rvll_handle {
     long long cap = 0;
     double*  d_theta = nullptr;
     double*  d_cube = nullptr;
-    double*  d_logL2[2] = {nullptr, nullptr};   // ping-pong: an all-gather may still read one
-    int      logl_cur = 0;                      // buffer the next launch writes
-    int      logl_last = 0;                     // buffer the last launch wrote (download source)
-    hipEvent_t ev_gather_done[2] = {nullptr, nullptr};
-    bool     gather_pending[2] = {false, false};
-    int32_t* d_flags = nullptr;
+    double*  d_logL2[2] = {nullptr, nullptr};   // one log-L buffer per pipeline lane
+    int      logl_cur = 0;                      // lane the next device-resident launch uses
+    int      logl_last = 0;                     // lane the last launch used (download source)
+    bool     theta_async = false;               // theta was (re)written asynchronously on lane 0's stream
+    int32_t* d_flags2[2] = {nullptr, nullptr};  // per lane, like log-L
 
     // pinned host staging for small transfers (scalar / small-batch callbacks)
     static constexpr size_t kPinBytes = 1u << 20;
@@ -150,13 +150,17 @@ struct rvll_handle {
     int n_cu = 256;
 
     // multi-GPU
-    void* nccl_comm = nullptr;
+    void* nccl_comm[2] = {nullptr, nullptr};    // one communicator per lane (the second by ncclCommSplit)
     int nranks = 1, rank = 0;
+    int nlanes = 1;
     long long gather_cap = 0;
-    double* d_gather = nullptr;
+    double* d_gather2[2] = {nullptr, nullptr};
+    int gather_last = 0;
 };
 
 namespace {
+
+hipStream_t lane_stream(const rvll_handle* h, int lane) { return lane == 0 ? h->compute : h->lane1; }
 
 int use_device(rvll_handle* h)
 {
@@ -291,17 +295,17 @@ int ensure_capacity(rvll_handle* h, long long B)
 {
     if (B <= h->cap) return RVLL_OK;
     long long cap = std::max<long long>(B, 1024);
-    if (h->comm) HIP_TRY(hipStreamSynchronize(h->comm));
+    if (h->lane1) HIP_TRY(hipStreamSynchronize(h->lane1));
     if (h->compute) HIP_TRY(hipStreamSynchronize(h->compute));
-    dev_free(h->d_theta); dev_free(h->d_cube); dev_free(h->d_logL2[0]); dev_free(h->d_logL2[1]); dev_free(h->d_flags);
-    h->gather_pending[0] = h->gather_pending[1] = false;
+    dev_free(h->d_theta); dev_free(h->d_cube); dev_free(h->d_logL2[0]); dev_free(h->d_logL2[1]); dev_free(h->d_flags2[0]); dev_free(h->d_flags2[1]);
     h->cap = 0;
     const size_t D = (size_t)std::max(1, h->L.ndim);
     HIP_TRY(hipMalloc(&h->d_theta, sizeof(double) * D * (size_t)cap));
     HIP_TRY(hipMalloc(&h->d_cube,  sizeof(double) * D * (size_t)cap));
     HIP_TRY(hipMalloc(&h->d_logL2[0], sizeof(double) * (size_t)cap));
     HIP_TRY(hipMalloc(&h->d_logL2[1], sizeof(double) * (size_t)cap));
-    HIP_TRY(hipMalloc(&h->d_flags, sizeof(int32_t) * (size_t)cap));
+    HIP_TRY(hipMalloc(&h->d_flags2[0], sizeof(int32_t) * (size_t)cap));
+    HIP_TRY(hipMalloc(&h->d_flags2[1], sizeof(int32_t) * (size_t)cap));
     h->cap = cap;
     return RVLL_OK;
 }
@@ -401,16 +405,7 @@ int rvll_create(const rvll_layout* layout, const double* time, const double* vra
     CREATE_TRY(hipGetDeviceProperties(&prop, device));
     h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     CREATE_TRY(hipStreamCreateWithFlags(&h->compute, hipStreamNonBlocking));
-    {
-        // the all-gather is a tiny kernel that must not queue behind the next saturating log-L launch:
-        // highest priority for the comm stream (numerically lowest value)
-        int prio_least = 0, prio_greatest = 0;
-        CREATE_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-        CREATE_TRY(hipStreamCreateWithPriority(&h->comm, hipStreamNonBlocking, prio_greatest));
-    }
-    CREATE_TRY(hipEventCreateWithFlags(&h->ev_compute_done, hipEventDisableTiming));
-    CREATE_TRY(hipEventCreateWithFlags(&h->ev_gather_done[0], hipEventDisableTiming));
-    CREATE_TRY(hipEventCreateWithFlags(&h->ev_gather_done[1], hipEventDisableTiming));
+    CREATE_TRY(hipStreamCreateWithFlags(&h->lane1, hipStreamNonBlocking));
     CREATE_TRY(hipHostMalloc(&h->pin_in, rvll_handle::kPinBytes, hipHostMallocMapped));
     CREATE_TRY(hipHostMalloc(&h->pin_out, rvll_handle::kPinBytes, hipHostMallocMapped));
     CREATE_TRY(hipHostGetDevicePointer(&h->pin_in_dev, h->pin_in, 0));
@@ -448,20 +443,18 @@ int rvll_destroy(rvll_handle* h)
 {
     if (!h) return RVLL_OK;
     (void)hipSetDevice(h->device);
-    if (h->nccl_comm && g_rccl.lib) { (void)g_rccl.CommDestroy(h->nccl_comm); h->nccl_comm = nullptr; }
     if (h->compute) (void)hipStreamSynchronize(h->compute);
-    if (h->comm) (void)hipStreamSynchronize(h->comm);
+    if (h->lane1) (void)hipStreamSynchronize(h->lane1);
+    for (auto& c : h->nccl_comm) if (c && g_rccl.lib) { (void)g_rccl.CommDestroy(c); c = nullptr; }
     free_priors(h);
-    dev_free(h->d_theta); dev_free(h->d_cube); dev_free(h->d_logL2[0]); dev_free(h->d_logL2[1]); dev_free(h->d_flags);
-    dev_free(h->d_gather);
-    for (auto& e : h->ev_gather_done) if (e) (void)hipEventDestroy(e);
+    dev_free(h->d_theta); dev_free(h->d_cube); dev_free(h->d_logL2[0]); dev_free(h->d_logL2[1]); dev_free(h->d_flags2[0]); dev_free(h->d_flags2[1]);
+    dev_free(h->d_gather2[0]); dev_free(h->d_gather2[1]);
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     dev_free(h->d_t); dev_free(h->d_y); dev_free(h->d_s2); dev_free(h->d_inst); dev_free(h->d_linpar);
     dev_free(h->d_planets); dev_free(h->d_insts); dev_free(h->d_linslots);
-    if (h->ev_compute_done) (void)hipEventDestroy(h->ev_compute_done);
     if (h->compute) (void)hipStreamDestroy(h->compute);
-    if (h->comm) (void)hipStreamDestroy(h->comm);
+    if (h->lane1) (void)hipStreamDestroy(h->lane1);
     delete h;
     return RVLL_OK;
 }
@@ -557,12 +550,14 @@ int rvll_dev_upload_theta(rvll_handle* h, const double* theta, int64_t B)
     if (B == 0) return RVLL_OK;
     if (!theta) return fail(RVLL_E_INVALID, "theta is null");
     const size_t nbytes = sizeof(double) * (size_t)B * (size_t)h->L.ndim;
+    HIP_TRY(hipStreamSynchronize(h->lane1));                        // lane 1 may still be reading the old theta
     if (nbytes <= rvll_handle::kPinBytes) {
         // small: stage through pinned memory (a true asynchronous DMA; the caller's buffer is free at once,
         // and every host-buffer call ends in a stream sync before the staging buffer is written again)
         HIP_TRY(hipStreamSynchronize(h->compute));
         memcpy(h->pin_in, theta, nbytes);
         HIP_TRY(hipMemcpyAsync(h->d_theta, h->pin_in, nbytes, hipMemcpyHostToDevice, h->compute));
+        h->theta_async = true;
         return RVLL_OK;
     }
     HIP_TRY(hipMemcpyAsync(h->d_theta, theta, nbytes, hipMemcpyHostToDevice, h->compute));
@@ -604,8 +599,10 @@ int rvll_dev_prior(rvll_handle* h, int64_t B)
     if (rc) return rc;
     if (!h->have_priors) return fail(RVLL_E_NOPRIORS, "rvll_set_priors has not been called");
     if (B < 0 || B > h->cap) return fail(RVLL_E_INVALID, "B %lld outside reserved capacity %lld", (long long)B, h->cap);
+    HIP_TRY(hipStreamSynchronize(h->lane1));                        // lane 1 may still be reading the old theta
     rvll::PriorArgs a{h->d_cube, h->d_theta, (long long)B, h->L.ndim, h->d_priors, h->d_heavy, h->n_heavy};
     HIP_TRY(rvll::launch_prior(a, h->compute));
+    h->theta_async = true;
     return RVLL_OK;
 }
 
@@ -615,16 +612,16 @@ int rvll_dev_loglike(rvll_handle* h, int64_t B)
     if (rc) return rc;
     if (B < 0 || B > h->cap) return fail(RVLL_E_INVALID, "B %lld outside reserved capacity %lld", (long long)B, h->cap);
     if (B == 0) return RVLL_OK;
-    const int buf = h->logl_cur;
-    if (h->gather_pending[buf]) {             // an all-gather may still be reading this buffer
-        HIP_TRY(hipStreamWaitEvent(h->compute, h->ev_gather_done[buf], 0));
-        h->gather_pending[buf] = false;
+    const int lane = h->logl_cur;
+    if (lane == 1 && h->theta_async) {        // theta was produced on lane 0's stream: order lane 1 behind it
+        HIP_TRY(hipStreamSynchronize(h->compute));
+        h->theta_async = false;
     }
     rvll::LoglikeArgs a;
-    rc = build_args(h, h->d_theta, h->d_logL2[buf], h->d_flags, B, &a);
+    rc = build_args(h, h->d_theta, h->d_logL2[lane], h->d_flags2[lane], B, &a);
     if (rc) return rc;
-    HIP_TRY(rvll::launch_loglike(a, h->compute));
-    h->logl_last = buf;
+    HIP_TRY(rvll::launch_loglike(a, lane_stream(h, lane)));
+    h->logl_last = lane;
     return RVLL_OK;
 }
 
@@ -633,6 +630,7 @@ int rvll_dev_download(rvll_handle* h, int64_t B, double* theta, double* logL, in
     int rc = use_device(h);
     if (rc) return rc;
     if (B < 0 || B > h->cap) return fail(RVLL_E_INVALID, "B %lld outside reserved capacity %lld", (long long)B, h->cap);
+    if (h->logl_last == 1) HIP_TRY(hipStreamSynchronize(h->lane1));   // results of lane 1 are read through lane 0's stream
     if (B > 0) {
         const size_t nt = theta ? sizeof(double) * (size_t)B * (size_t)h->L.ndim : 0;
         const size_t nl = logL ? sizeof(double) * (size_t)B : 0;
@@ -641,7 +639,7 @@ int rvll_dev_download(rvll_handle* h, int64_t B, double* theta, double* logL, in
             char* p = static_cast<char*>(h->pin_out);
             if (nt) HIP_TRY(hipMemcpyAsync(p, h->d_theta, nt, hipMemcpyDeviceToHost, h->compute));
             if (nl) HIP_TRY(hipMemcpyAsync(p + nt, h->d_logL2[h->logl_last], nl, hipMemcpyDeviceToHost, h->compute));
-            if (nf) HIP_TRY(hipMemcpyAsync(p + nt + nl, h->d_flags, nf, hipMemcpyDeviceToHost, h->compute));
+            if (nf) HIP_TRY(hipMemcpyAsync(p + nt + nl, h->d_flags2[h->logl_last], nf, hipMemcpyDeviceToHost, h->compute));
             HIP_TRY(hipStreamSynchronize(h->compute));
             if (nt) memcpy(theta, p, nt);
             if (nl) memcpy(logL, p + nt, nl);
@@ -650,7 +648,7 @@ int rvll_dev_download(rvll_handle* h, int64_t B, double* theta, double* logL, in
         }
         if (theta) HIP_TRY(hipMemcpyAsync(theta, h->d_theta, nt, hipMemcpyDeviceToHost, h->compute));
         if (logL)  HIP_TRY(hipMemcpyAsync(logL, h->d_logL2[h->logl_last], nl, hipMemcpyDeviceToHost, h->compute));
-        if (flags) HIP_TRY(hipMemcpyAsync(flags, h->d_flags, nf, hipMemcpyDeviceToHost, h->compute));
+        if (flags) HIP_TRY(hipMemcpyAsync(flags, h->d_flags2[h->logl_last], nf, hipMemcpyDeviceToHost, h->compute));
     }
     HIP_TRY(hipStreamSynchronize(h->compute));
     return RVLL_OK;
@@ -661,8 +659,16 @@ int rvll_dev_sync(rvll_handle* h)
     int rc = use_device(h);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->compute));
-    HIP_TRY(hipStreamSynchronize(h->comm));
+    HIP_TRY(hipStreamSynchronize(h->lane1));
+    h->theta_async = false;
     return RVLL_OK;
+}
+
+int rvll_dev_flip_lane(rvll_handle* h)
+{
+    if (!h) return fail(RVLL_E_INVALID, "null handle");
+    h->logl_cur ^= 1;
+    return h->logl_cur;
 }
 
 int rvll_dev_time_loglike(rvll_handle* h, int64_t B, int32_t warmup, int32_t iters, rvll_timing* out)
@@ -672,9 +678,10 @@ int rvll_dev_time_loglike(rvll_handle* h, int64_t B, int32_t warmup, int32_t ite
     if (!out || iters < 1 || warmup < 0) return fail(RVLL_E_INVALID, "bad timing arguments");
     if (B < 1 || B > h->cap) return fail(RVLL_E_INVALID, "B %lld outside reserved capacity %lld", (long long)B, h->cap);
     rvll::LoglikeArgs a;
-    rc = build_args(h, h->d_theta, h->d_logL2[h->logl_cur], h->d_flags, B, &a);
+    HIP_TRY(hipStreamSynchronize(h->lane1));
+    rc = build_args(h, h->d_theta, h->d_logL2[0], h->d_flags2[0], B, &a);
     if (rc) return rc;
-    h->logl_last = h->logl_cur;
+    h->logl_last = 0;
     for (int i = 0; i < warmup; ++i) HIP_TRY(rvll::launch_loglike(a, h->compute));
     std::vector<hipEvent_t> ev((size_t)iters + 1, nullptr);
     int status = RVLL_OK;
@@ -822,7 +829,7 @@ int rvll_kep_rv_batch(rvll_handle* h, const double* theta, int64_t B, const doub
     if (e == hipSuccess) e = hipMemcpyAsync(d_times, times, sizeof(double) * (size_t)n_times, hipMemcpyHostToDevice, h->compute);
     if (e == hipSuccess) {
         rvll::LoglikeArgs a;
-        status = build_args(h, h->d_theta, h->d_logL2[h->logl_cur], h->d_flags, B, &a);
+        status = build_args(h, h->d_theta, h->d_logL2[0], h->d_flags2[0], B, &a);
         if (status == RVLL_OK) e = rvll::launch_keprv(a, d_times, n_times, include_mask, d_out, h->compute);
     }
     if (status == RVLL_OK && e == hipSuccess)
@@ -876,37 +883,51 @@ int rvll_comm_init(rvll_handle* h, const unsigned char id[RVLL_COMM_ID_BYTES], i
     if (!id || nranks < 1 || rank < 0 || rank >= nranks) return fail(RVLL_E_INVALID, "bad comm arguments");
     rc = rccl_load();
     if (rc) return rc;
-    if (h->nccl_comm) { (void)g_rccl.CommDestroy(h->nccl_comm); h->nccl_comm = nullptr; }
+    rc = rvll_comm_destroy(h);
+    if (rc) return rc;
     Id128 u;
     memcpy(u.bytes, id, RVLL_COMM_ID_BYTES);
-    RCCL_TRY(g_rccl.CommInitRank(&h->nccl_comm, nranks, u, rank));
+    RCCL_TRY(g_rccl.CommInitRank(&h->nccl_comm[0], nranks, u, rank));
     h->nranks = nranks;
     h->rank = rank;
+    h->nlanes = 1;
+    // second pipeline lane: its own communicator (collectives of ONE communicator must not run concurrently on
+    // two streams), derived collectively from the first — no second id exchange.  Without ncclCommSplit the
+    // step degrades to one lane: the gather then runs in-stream behind its kernel, still correct.
+    if (g_rccl.CommSplit && g_rccl.CommSplit(h->nccl_comm[0], 0, rank, &h->nccl_comm[1], nullptr) == 0 && h->nccl_comm[1])
+        h->nlanes = 2;
+    else
+        h->nccl_comm[1] = nullptr;
+    h->logl_cur = 0;
     return RVLL_OK;
 }
 
+// One multi-GPU step is  rvll_dev_loglike(B_local) ; rvll_allgather_logl(B_local).  Steps alternate between two
+// pipeline LANES, each with its own stream, communicator, log-L and gather buffer: the gather of step k runs
+// in-stream right behind kernel k on lane (k mod 2) while kernel k+1 runs on the other lane, so collective
+// latency hides behind compute without any cross-stream event (measured on MI355X: event record + stream wait
+// pairs cost ~10 us per step, an in-stream gather ~2 us; scripts/comm_overhead_probe.py).
 int rvll_allgather_logl(rvll_handle* h, int64_t B_local)
 {
     int rc = use_device(h);
     if (rc) return rc;
-    if (!h->nccl_comm) return fail(RVLL_E_RCCL, "rvll_comm_init has not been called");
+    if (!h->nccl_comm[0]) return fail(RVLL_E_RCCL, "rvll_comm_init has not been called");
     if (B_local < 1 || B_local > h->cap) return fail(RVLL_E_INVALID, "B_local %lld outside reserved capacity %lld", (long long)B_local, h->cap);
     const long long total = (long long)B_local * h->nranks;
     if (total > h->gather_cap) {
-        HIP_TRY(hipStreamSynchronize(h->comm));
-        dev_free(h->d_gather);
+        HIP_TRY(hipStreamSynchronize(h->compute));
+        HIP_TRY(hipStreamSynchronize(h->lane1));
+        dev_free(h->d_gather2[0]); dev_free(h->d_gather2[1]);
         h->gather_cap = 0;
-        HIP_TRY(hipMalloc(&h->d_gather, sizeof(double) * (size_t)total));
+        HIP_TRY(hipMalloc(&h->d_gather2[0], sizeof(double) * (size_t)total));
+        HIP_TRY(hipMalloc(&h->d_gather2[1], sizeof(double) * (size_t)total));
         h->gather_cap = total;
     }
-    // comm stream waits for the log-L kernel; the next batch's kernel may start meanwhile
-    HIP_TRY(hipEventRecord(h->ev_compute_done, h->compute));
-    HIP_TRY(hipStreamWaitEvent(h->comm, h->ev_compute_done, 0));
-    const int buf = h->logl_last;             // what the last launch wrote
-    RCCL_TRY(g_rccl.AllGather(h->d_logL2[buf], h->d_gather, (size_t)B_local, kNcclFloat64, h->nccl_comm, h->comm));
-    HIP_TRY(hipEventRecord(h->ev_gather_done[buf], h->comm));
-    h->gather_pending[buf] = true;
-    h->logl_cur = buf ^ 1;                    // the next launch writes the other buffer
+    const int lane = h->logl_last;            // the lane whose kernel just wrote its log-L
+    RCCL_TRY(g_rccl.AllGather(h->d_logL2[lane], h->d_gather2[lane], (size_t)B_local, kNcclFloat64,
+                              h->nccl_comm[lane], lane_stream(h, lane)));
+    h->gather_last = lane;
+    if (h->nlanes > 1) h->logl_cur = lane ^ 1;      // the next step runs on the other lane
     return RVLL_OK;
 }
 
@@ -915,8 +936,9 @@ int rvll_download_gathered(rvll_handle* h, int64_t B_total, double* logL_all)
     int rc = use_device(h);
     if (rc) return rc;
     if (!logL_all || B_total < 1 || B_total > h->gather_cap) return fail(RVLL_E_INVALID, "bad gathered download");
-    HIP_TRY(hipMemcpyAsync(logL_all, h->d_gather, sizeof(double) * (size_t)B_total, hipMemcpyDeviceToHost, h->comm));
-    HIP_TRY(hipStreamSynchronize(h->comm));
+    hipStream_t st = lane_stream(h, h->gather_last);
+    HIP_TRY(hipMemcpyAsync(logL_all, h->d_gather2[h->gather_last], sizeof(double) * (size_t)B_total, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     return RVLL_OK;
 }
 
@@ -924,13 +946,16 @@ int rvll_comm_destroy(rvll_handle* h)
 {
     int rc = use_device(h);
     if (rc) return rc;
-    if (h->nccl_comm && g_rccl.lib) {
-        HIP_TRY(hipStreamSynchronize(h->comm));
-        RCCL_TRY(g_rccl.CommDestroy(h->nccl_comm));
+    HIP_TRY(hipStreamSynchronize(h->compute));
+    HIP_TRY(hipStreamSynchronize(h->lane1));
+    for (int lane = 1; lane >= 0; --lane) {
+        if (h->nccl_comm[lane] && g_rccl.lib) RCCL_TRY(g_rccl.CommDestroy(h->nccl_comm[lane]));
+        h->nccl_comm[lane] = nullptr;
     }
-    h->nccl_comm = nullptr;
     h->nranks = 1;
     h->rank = 0;
+    h->nlanes = 1;
+    h->logl_cur = 0;
     return RVLL_OK;
 }
 

@@ -202,6 +202,10 @@ class GpuRVModel:
     def dev_loglike(self, n):
         _abi.check(self._lib.rvll_dev_loglike(self._h, int(n)))
 
+    def dev_flip_lane(self):
+        """Alternate the pipeline lane between independent device-resident batches (include/rvll.h)."""
+        return self._lib.rvll_dev_flip_lane(self._h)
+
     def dev_sync(self):
         _abi.check(self._lib.rvll_dev_sync(self._h))
 

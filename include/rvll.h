@@ -220,6 +220,10 @@ int rvll_dev_loglike(rvll_handle* h, int64_t B);               /* theta -> logL 
 int rvll_dev_download(rvll_handle* h, int64_t B, double* theta /*or NULL*/,
                       double* logL /*or NULL*/, int32_t* flags /*or NULL*/);
 int rvll_dev_sync(rvll_handle* h);
+/* Device-resident launches run on one of two pipeline lanes (own stream, log-L and flags buffer each).  Flipping
+ * the lane between independent batches keeps two launches in flight, so one batch's ramp-up hides the previous
+ * one's tail; rvll_allgather_logl flips it by itself.  Returns the lane (0/1) the next launch will use.       */
+int rvll_dev_flip_lane(rvll_handle* h);
 /* Time `iters` log-L launches over the resident theta with HIP events on the
  * compute stream (after `warmup` untimed launches).                          */
 int rvll_dev_time_loglike(rvll_handle* h, int64_t B, int32_t warmup, int32_t iters,
@@ -235,9 +239,11 @@ int rvll_set_points_per_block(rvll_handle* h, int32_t points_per_block);
 int rvll_comm_unique_id(unsigned char id[RVLL_COMM_ID_BYTES]);
 int rvll_comm_init(rvll_handle* h, const unsigned char id[RVLL_COMM_ID_BYTES],
                    int32_t nranks, int32_t rank);
-/* All ranks hold B_local resident log-L values; gathers nranks*B_local values
- * on the device (rank-major) on the comm stream, ordered after the compute
- * stream's work.  Asynchronous.                                               */
+/* One multi-GPU step is rvll_dev_loglike(B_local) followed by rvll_allgather_logl(B_local): every rank's
+ * per-shard log-L (the buffer the kernel just wrote) is all-gathered on the device, rank-major, so that every
+ * rank — rank 0 owns the sampler's replacement step — holds all nranks*B_local values.  Asynchronous.  Steps
+ * alternate between two pipeline lanes (own stream, communicator and buffers each), so the gather of one step
+ * overlaps the kernel of the next without cross-stream events; rvll_download_gathered returns the last one. */
 int rvll_allgather_logl(rvll_handle* h, int64_t B_local);
 int rvll_download_gathered(rvll_handle* h, int64_t B_total, double* logL_all);
 int rvll_comm_destroy(rvll_handle* h);

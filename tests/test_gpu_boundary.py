@@ -154,3 +154,35 @@ def test_single_process_multi_handle_sharding(gpu_required):
         t1, l1 = one.prior_loglike_batch(cube)
         t2, l2 = multi.prior_loglike_batch(cube)
         assert np.array_equal(t1, t2) and np.array_equal(l1, l2)
+
+
+def test_pipeline_lanes_give_identical_results_and_order_theta_updates(gpu_required):
+    """Device-resident launches alternate between two lanes (streams + buffers).  Either lane must produce the
+    same log-L, and a theta upload / prior launch (lane 0's stream) must be seen by a following lane-1 launch."""
+    w = make_workload(3)
+    t1, t2 = w.sample_theta(3000, seed=21), w.sample_theta(3000, seed=22)
+    with GpuRVModel(w.fixedpardict, w.table, w.parnames, priordict=w.priordict()) as m:
+        want1, want2 = m.log_likelihood_batch(t1), m.log_likelihood_batch(t2)
+        m.dev_upload_theta(t1)
+        m.dev_loglike(3000)                                   # lane 0
+        assert m.dev_flip_lane() == 1
+        m.dev_upload_theta(t2)                                # async copy on lane 0's stream ...
+        m.dev_loglike(3000)                                   # ... must be visible to this lane-1 launch
+        assert np.array_equal(m.dev_download(3000)[1], want2)
+        assert m.dev_flip_lane() == 0
+        m.dev_upload_theta(t1)                                # waits for lane 1's readers before overwriting theta
+        m.dev_loglike(3000)
+        assert np.array_equal(m.dev_download(3000)[1], want1)
+        for _ in range(7):                                    # many launches in flight on alternating lanes
+            m.dev_loglike(3000)
+            m.dev_flip_lane()
+        m.dev_sync()
+        if m.dev_flip_lane() != 0:
+            m.dev_flip_lane()
+        cube = w.sample_cube(3000, 1)
+        m.dev_upload_cube(cube)
+        m.dev_prior(3000)
+        m.dev_flip_lane()
+        m.dev_loglike(3000)                                   # lane 1 behind the prior kernel on lane 0
+        theta, logl, _ = m.dev_download(3000, theta=True)
+        assert np.array_equal(logl, m.log_likelihood_batch(theta))
