@@ -278,7 +278,12 @@ def main():
             "config": {"workload": WORKLOAD_TEXT[args.config].format(b=B), "cfg": args.config,
                        "live_points_per_gpu": B, "epochs": w.table.n_epochs, "planets": len(model.layout.planets),
                        "instruments": len(w.table.insts), "free_parameters": w.ndim,
-                       "parallelism": f"live-point shards x{world}", "allgather": gather},
+                       "parallelism": f"live-point shards x{world}", "allgather": gather,
+                       "step_structure": ("one stream: launch k+1 starts when launch k has drained (value == B / kernel time)"
+                                          if world == 1 else
+                                          "two pipeline lanes (stream + communicator + buffers each): kernel ; all-gather "
+                                          "in-stream, consecutive steps alternate lanes, so two launches are in flight; "
+                                          "the N=1 equivalent is two_lane_pipelined_evals_per_s of the N=1 line")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.config, B),
                          "kernel": "loglike_kernel", "kernel_ms_mean": tm["kernel_ms_mean"],
