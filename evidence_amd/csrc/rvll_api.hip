@@ -133,6 +133,7 @@ struct rvll_handle {
     int      logl_cur = 0;                      // lane the next device-resident launch uses
     int      logl_last = 0;                     // lane the last launch used (download source)
     bool     theta_async = false;               // theta was (re)written asynchronously on lane 0's stream
+    bool     pipelined = false;                 // launches alternate lanes: two are in flight, no kernel-end tail
     int32_t* d_flags2[2] = {nullptr, nullptr};  // per lane, like log-L
 
     // pinned host staging for small transfers (scalar / small-batch callbacks)
@@ -246,7 +247,8 @@ int choose_points_per_block(rvll_handle* h, long long B)
         const double W = (double)((items + rvll::kWave - 1) / rvll::kWave) / 4.0 + 0.6 + 0.5 * (chunks - 1.0);
         const double blocks = std::ceil((double)B / pb);
         const int occ = rvll::loglike_blocks_per_cu(lds);
-        double remaining = std::ceil(blocks / h->n_cu), cost = 0.5 * W;
+        // with two launches in flight (pipeline lanes) the next launch fills the tail, so the tail term drops out
+        double remaining = std::ceil(blocks / h->n_cu), cost = h->pipelined ? 0.0 : 0.5 * W;
         while (remaining > 0) {
             const double k = std::min((double)occ, remaining);
             const double pen = k >= 4 ? 1.0 : k >= 3 ? 1.08 : k >= 2 ? 1.25 : 1.6;
@@ -668,6 +670,7 @@ int rvll_dev_flip_lane(rvll_handle* h)
 {
     if (!h) return fail(RVLL_E_INVALID, "null handle");
     h->logl_cur ^= 1;
+    if (!h->pipelined) { h->pipelined = true; h->geo_B = -1; }
     return h->logl_cur;
 }
 
@@ -927,7 +930,10 @@ int rvll_allgather_logl(rvll_handle* h, int64_t B_local)
     RCCL_TRY(g_rccl.AllGather(h->d_logL2[lane], h->d_gather2[lane], (size_t)B_local, kNcclFloat64,
                               h->nccl_comm[lane], lane_stream(h, lane)));
     h->gather_last = lane;
-    if (h->nlanes > 1) h->logl_cur = lane ^ 1;      // the next step runs on the other lane
+    if (h->nlanes > 1) {
+        h->logl_cur = lane ^ 1;               // the next step runs on the other lane
+        if (!h->pipelined) { h->pipelined = true; h->geo_B = -1; }
+    }
     return RVLL_OK;
 }
 
