@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -897,7 +898,8 @@ int rvll_comm_init(rvll_handle* h, const unsigned char id[RVLL_COMM_ID_BYTES], i
     // second pipeline lane: its own communicator (collectives of ONE communicator must not run concurrently on
     // two streams), derived collectively from the first — no second id exchange.  Without ncclCommSplit the
     // step degrades to one lane: the gather then runs in-stream behind its kernel, still correct.
-    if (g_rccl.CommSplit && g_rccl.CommSplit(h->nccl_comm[0], 0, rank, &h->nccl_comm[1], nullptr) == 0 && h->nccl_comm[1])
+    const bool single_lane = getenv("RVLL_SINGLE_LANE") != nullptr;      // test switch for the degraded path
+    if (!single_lane && g_rccl.CommSplit && g_rccl.CommSplit(h->nccl_comm[0], 0, rank, &h->nccl_comm[1], nullptr) == 0 && h->nccl_comm[1])
         h->nlanes = 2;
     else
         h->nccl_comm[1] = nullptr;

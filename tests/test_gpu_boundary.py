@@ -186,3 +186,19 @@ def test_pipeline_lanes_give_identical_results_and_order_theta_updates(gpu_requi
         m.dev_loglike(3000)                                   # lane 1 behind the prior kernel on lane 0
         theta, logl, _ = m.dev_download(3000, theta=True)
         assert np.array_equal(logl, m.log_likelihood_batch(theta))
+
+
+def test_single_lane_fallback_gathers_in_stream(gpu_required, monkeypatch):
+    """Without ncclCommSplit (forced here with RVLL_SINGLE_LANE) the step degrades to one lane: the gather runs
+    in-stream behind its kernel.  Same values."""
+    monkeypatch.setenv("RVLL_SINGLE_LANE", "1")
+    case = golden.config_case(3)
+    with GpuRVModel(case.fixed, case.table, case.parnames) as m:
+        m.comm_init(GpuRVModel.comm_unique_id(), 1, 0)
+        want = m.log_likelihood_batch(case.theta)
+        m.dev_upload_theta(case.theta)
+        for _ in range(4):
+            m.dev_loglike(len(case.theta))
+            m.allgather_logl(len(case.theta))
+        assert np.array_equal(m.download_gathered(len(case.theta)), want)
+        m.comm_destroy()
