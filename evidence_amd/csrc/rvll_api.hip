@@ -96,10 +96,13 @@ void dev_free(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
 
 }  // namespace
 
+constexpr int kMaxLanes = 4;
+
 struct rvll_handle {
     int device = 0;
     hipStream_t compute = nullptr;          // lane 0: every single-GPU call runs here
-    hipStream_t lane1 = nullptr;            // lane 1: the second pipeline lane of the multi-GPU step (see rvll_allgather_logl)
+    hipStream_t lanes[kMaxLanes] = {};      // lanes[0] == compute; further pipeline lanes of the multi-GPU step (rvll_allgather_logl)
+    int      nlanes_dev = 2;                // lanes rvll_dev_flip_lane cycles through
 
     // layout (host mirror, then device copies)
     rvll_layout L{};
@@ -130,12 +133,12 @@ struct rvll_handle {
     long long cap = 0;
     double*  d_theta = nullptr;
     double*  d_cube = nullptr;
-    double*  d_logL2[2] = {nullptr, nullptr};   // one log-L buffer per pipeline lane
+    double*  d_logL2[kMaxLanes] = {};           // one log-L buffer per pipeline lane
     int      logl_cur = 0;                      // lane the next device-resident launch uses
     int      logl_last = 0;                     // lane the last launch used (download source)
     bool     theta_async = false;               // theta was (re)written asynchronously on lane 0's stream
     bool     pipelined = false;                 // launches alternate lanes: two are in flight, no kernel-end tail
-    int32_t* d_flags2[2] = {nullptr, nullptr};  // per lane, like log-L
+    int32_t* d_flags2[kMaxLanes] = {};          // per lane, like log-L
 
     // pinned host staging for small transfers (scalar / small-batch callbacks)
     static constexpr size_t kPinBytes = 1u << 20;
@@ -152,17 +155,24 @@ struct rvll_handle {
     int n_cu = 256;
 
     // multi-GPU
-    void* nccl_comm[2] = {nullptr, nullptr};    // one communicator per lane (the second by ncclCommSplit)
+    void* nccl_comm[kMaxLanes] = {};            // one communicator per lane (all but the first by ncclCommSplit)
     int nranks = 1, rank = 0;
     int nlanes = 1;
     long long gather_cap = 0;
-    double* d_gather2[2] = {nullptr, nullptr};
+    double* d_gather2[kMaxLanes] = {};
     int gather_last = 0;
 };
 
 namespace {
 
-hipStream_t lane_stream(const rvll_handle* h, int lane) { return lane == 0 ? h->compute : h->lane1; }
+hipStream_t lane_stream(const rvll_handle* h, int lane) { return h->lanes[lane]; }
+
+int sync_other_lanes(rvll_handle* h)
+{
+    for (int l = 1; l < kMaxLanes; ++l)
+        if (h->lanes[l]) HIP_TRY(hipStreamSynchronize(h->lanes[l]));
+    return RVLL_OK;
+}
 
 int use_device(rvll_handle* h)
 {
@@ -298,17 +308,18 @@ int ensure_capacity(rvll_handle* h, long long B)
 {
     if (B <= h->cap) return RVLL_OK;
     long long cap = std::max<long long>(B, 1024);
-    if (h->lane1) HIP_TRY(hipStreamSynchronize(h->lane1));
+    { int rc_ = sync_other_lanes(h); if (rc_) return rc_; }
     if (h->compute) HIP_TRY(hipStreamSynchronize(h->compute));
-    dev_free(h->d_theta); dev_free(h->d_cube); dev_free(h->d_logL2[0]); dev_free(h->d_logL2[1]); dev_free(h->d_flags2[0]); dev_free(h->d_flags2[1]);
+    dev_free(h->d_theta); dev_free(h->d_cube);
+    for (int l = 0; l < kMaxLanes; ++l) { dev_free(h->d_logL2[l]); dev_free(h->d_flags2[l]); }
     h->cap = 0;
     const size_t D = (size_t)std::max(1, h->L.ndim);
     HIP_TRY(hipMalloc(&h->d_theta, sizeof(double) * D * (size_t)cap));
     HIP_TRY(hipMalloc(&h->d_cube,  sizeof(double) * D * (size_t)cap));
-    HIP_TRY(hipMalloc(&h->d_logL2[0], sizeof(double) * (size_t)cap));
-    HIP_TRY(hipMalloc(&h->d_logL2[1], sizeof(double) * (size_t)cap));
-    HIP_TRY(hipMalloc(&h->d_flags2[0], sizeof(int32_t) * (size_t)cap));
-    HIP_TRY(hipMalloc(&h->d_flags2[1], sizeof(int32_t) * (size_t)cap));
+    for (int l = 0; l < kMaxLanes; ++l) {
+        HIP_TRY(hipMalloc(&h->d_logL2[l], sizeof(double) * (size_t)cap));
+        HIP_TRY(hipMalloc(&h->d_flags2[l], sizeof(int32_t) * (size_t)cap));
+    }
     h->cap = cap;
     return RVLL_OK;
 }
@@ -408,7 +419,9 @@ int rvll_create(const rvll_layout* layout, const double* time, const double* vra
     CREATE_TRY(hipGetDeviceProperties(&prop, device));
     h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     CREATE_TRY(hipStreamCreateWithFlags(&h->compute, hipStreamNonBlocking));
-    CREATE_TRY(hipStreamCreateWithFlags(&h->lane1, hipStreamNonBlocking));
+    h->lanes[0] = h->compute;
+    for (int l = 1; l < kMaxLanes; ++l) CREATE_TRY(hipStreamCreateWithFlags(&h->lanes[l], hipStreamNonBlocking));
+    if (const char* e = getenv("RVLL_LANES")) h->nlanes_dev = std::max(1, std::min(kMaxLanes, atoi(e)));
     CREATE_TRY(hipHostMalloc(&h->pin_in, rvll_handle::kPinBytes, hipHostMallocMapped));
     CREATE_TRY(hipHostMalloc(&h->pin_out, rvll_handle::kPinBytes, hipHostMallocMapped));
     CREATE_TRY(hipHostGetDevicePointer(&h->pin_in_dev, h->pin_in, 0));
@@ -447,17 +460,17 @@ int rvll_destroy(rvll_handle* h)
     if (!h) return RVLL_OK;
     (void)hipSetDevice(h->device);
     if (h->compute) (void)hipStreamSynchronize(h->compute);
-    if (h->lane1) (void)hipStreamSynchronize(h->lane1);
+    (void)sync_other_lanes(h);
     for (auto& c : h->nccl_comm) if (c && g_rccl.lib) { (void)g_rccl.CommDestroy(c); c = nullptr; }
     free_priors(h);
-    dev_free(h->d_theta); dev_free(h->d_cube); dev_free(h->d_logL2[0]); dev_free(h->d_logL2[1]); dev_free(h->d_flags2[0]); dev_free(h->d_flags2[1]);
-    dev_free(h->d_gather2[0]); dev_free(h->d_gather2[1]);
+    dev_free(h->d_theta); dev_free(h->d_cube);
+    for (int l = 0; l < kMaxLanes; ++l) { dev_free(h->d_logL2[l]); dev_free(h->d_flags2[l]); dev_free(h->d_gather2[l]); }
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     dev_free(h->d_t); dev_free(h->d_y); dev_free(h->d_s2); dev_free(h->d_inst); dev_free(h->d_linpar);
     dev_free(h->d_planets); dev_free(h->d_insts); dev_free(h->d_linslots);
+    for (int l = 1; l < kMaxLanes; ++l) if (h->lanes[l]) (void)hipStreamDestroy(h->lanes[l]);
     if (h->compute) (void)hipStreamDestroy(h->compute);
-    if (h->lane1) (void)hipStreamDestroy(h->lane1);
     delete h;
     return RVLL_OK;
 }
@@ -553,7 +566,8 @@ int rvll_dev_upload_theta(rvll_handle* h, const double* theta, int64_t B)
     if (B == 0) return RVLL_OK;
     if (!theta) return fail(RVLL_E_INVALID, "theta is null");
     const size_t nbytes = sizeof(double) * (size_t)B * (size_t)h->L.ndim;
-    HIP_TRY(hipStreamSynchronize(h->lane1));                        // lane 1 may still be reading the old theta
+    rc = sync_other_lanes(h);                                       // other lanes may still be reading the old theta
+    if (rc) return rc;
     if (nbytes <= rvll_handle::kPinBytes) {
         // small: stage through pinned memory (a true asynchronous DMA; the caller's buffer is free at once,
         // and every host-buffer call ends in a stream sync before the staging buffer is written again)
@@ -602,7 +616,8 @@ int rvll_dev_prior(rvll_handle* h, int64_t B)
     if (rc) return rc;
     if (!h->have_priors) return fail(RVLL_E_NOPRIORS, "rvll_set_priors has not been called");
     if (B < 0 || B > h->cap) return fail(RVLL_E_INVALID, "B %lld outside reserved capacity %lld", (long long)B, h->cap);
-    HIP_TRY(hipStreamSynchronize(h->lane1));                        // lane 1 may still be reading the old theta
+    rc = sync_other_lanes(h);                                       // other lanes may still be reading the old theta
+    if (rc) return rc;
     rvll::PriorArgs a{h->d_cube, h->d_theta, (long long)B, h->L.ndim, h->d_priors, h->d_heavy, h->n_heavy};
     HIP_TRY(rvll::launch_prior(a, h->compute));
     h->theta_async = true;
@@ -616,7 +631,7 @@ int rvll_dev_loglike(rvll_handle* h, int64_t B)
     if (B < 0 || B > h->cap) return fail(RVLL_E_INVALID, "B %lld outside reserved capacity %lld", (long long)B, h->cap);
     if (B == 0) return RVLL_OK;
     const int lane = h->logl_cur;
-    if (lane == 1 && h->theta_async) {        // theta was produced on lane 0's stream: order lane 1 behind it
+    if (lane != 0 && h->theta_async) {        // theta was produced on lane 0's stream: order this lane behind it
         HIP_TRY(hipStreamSynchronize(h->compute));
         h->theta_async = false;
     }
@@ -633,7 +648,7 @@ int rvll_dev_download(rvll_handle* h, int64_t B, double* theta, double* logL, in
     int rc = use_device(h);
     if (rc) return rc;
     if (B < 0 || B > h->cap) return fail(RVLL_E_INVALID, "B %lld outside reserved capacity %lld", (long long)B, h->cap);
-    if (h->logl_last == 1) HIP_TRY(hipStreamSynchronize(h->lane1));   // results of lane 1 are read through lane 0's stream
+    if (h->logl_last != 0) HIP_TRY(hipStreamSynchronize(h->lanes[h->logl_last]));   // read through lane 0's stream
     if (B > 0) {
         const size_t nt = theta ? sizeof(double) * (size_t)B * (size_t)h->L.ndim : 0;
         const size_t nl = logL ? sizeof(double) * (size_t)B : 0;
@@ -662,7 +677,8 @@ int rvll_dev_sync(rvll_handle* h)
     int rc = use_device(h);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->compute));
-    HIP_TRY(hipStreamSynchronize(h->lane1));
+    rc = sync_other_lanes(h);
+    if (rc) return rc;
     h->theta_async = false;
     return RVLL_OK;
 }
@@ -670,7 +686,7 @@ int rvll_dev_sync(rvll_handle* h)
 int rvll_dev_flip_lane(rvll_handle* h)
 {
     if (!h) return fail(RVLL_E_INVALID, "null handle");
-    h->logl_cur ^= 1;
+    h->logl_cur = (h->logl_cur + 1) % (h->nccl_comm[0] ? h->nlanes : h->nlanes_dev);
     if (!h->pipelined) { h->pipelined = true; h->geo_B = -1; }
     return h->logl_cur;
 }
@@ -682,7 +698,8 @@ int rvll_dev_time_loglike(rvll_handle* h, int64_t B, int32_t warmup, int32_t ite
     if (!out || iters < 1 || warmup < 0) return fail(RVLL_E_INVALID, "bad timing arguments");
     if (B < 1 || B > h->cap) return fail(RVLL_E_INVALID, "B %lld outside reserved capacity %lld", (long long)B, h->cap);
     rvll::LoglikeArgs a;
-    HIP_TRY(hipStreamSynchronize(h->lane1));
+    rc = sync_other_lanes(h);
+    if (rc) return rc;
     rc = build_args(h, h->d_theta, h->d_logL2[0], h->d_flags2[0], B, &a);
     if (rc) return rc;
     h->logl_last = 0;
@@ -895,14 +912,19 @@ int rvll_comm_init(rvll_handle* h, const unsigned char id[RVLL_COMM_ID_BYTES], i
     h->nranks = nranks;
     h->rank = rank;
     h->nlanes = 1;
-    // second pipeline lane: its own communicator (collectives of ONE communicator must not run concurrently on
-    // two streams), derived collectively from the first — no second id exchange.  Without ncclCommSplit the
-    // step degrades to one lane: the gather then runs in-stream behind its kernel, still correct.
-    const bool single_lane = getenv("RVLL_SINGLE_LANE") != nullptr;      // test switch for the degraded path
-    if (!single_lane && g_rccl.CommSplit && g_rccl.CommSplit(h->nccl_comm[0], 0, rank, &h->nccl_comm[1], nullptr) == 0 && h->nccl_comm[1])
-        h->nlanes = 2;
-    else
-        h->nccl_comm[1] = nullptr;
+    // further pipeline lanes: one communicator each (collectives of ONE communicator must not run concurrently
+    // on two streams), derived collectively from the first — no further id exchange.  Without ncclCommSplit
+    // the step degrades to one lane: the gather then runs in-stream behind its kernel, still correct.
+    int want = 3;                                             // two kernels stay in flight while one lane gathers
+    if (const char* e = getenv("RVLL_LANES")) want = std::max(1, std::min(kMaxLanes, atoi(e)));
+    if (getenv("RVLL_SINGLE_LANE")) want = 1;                 // test switch for the degraded path
+    for (int l = 1; l < want; ++l) {
+        if (!g_rccl.CommSplit || g_rccl.CommSplit(h->nccl_comm[0], 0, rank, &h->nccl_comm[l], nullptr) != 0 || !h->nccl_comm[l]) {
+            h->nccl_comm[l] = nullptr;
+            break;
+        }
+        h->nlanes = l + 1;
+    }
     h->logl_cur = 0;
     return RVLL_OK;
 }
@@ -921,11 +943,11 @@ int rvll_allgather_logl(rvll_handle* h, int64_t B_local)
     const long long total = (long long)B_local * h->nranks;
     if (total > h->gather_cap) {
         HIP_TRY(hipStreamSynchronize(h->compute));
-        HIP_TRY(hipStreamSynchronize(h->lane1));
-        dev_free(h->d_gather2[0]); dev_free(h->d_gather2[1]);
+        rc = sync_other_lanes(h);
+        if (rc) return rc;
+        for (int l = 0; l < kMaxLanes; ++l) dev_free(h->d_gather2[l]);
         h->gather_cap = 0;
-        HIP_TRY(hipMalloc(&h->d_gather2[0], sizeof(double) * (size_t)total));
-        HIP_TRY(hipMalloc(&h->d_gather2[1], sizeof(double) * (size_t)total));
+        for (int l = 0; l < h->nlanes; ++l) HIP_TRY(hipMalloc(&h->d_gather2[l], sizeof(double) * (size_t)total));
         h->gather_cap = total;
     }
     const int lane = h->logl_last;            // the lane whose kernel just wrote its log-L
@@ -933,7 +955,7 @@ int rvll_allgather_logl(rvll_handle* h, int64_t B_local)
                               h->nccl_comm[lane], lane_stream(h, lane)));
     h->gather_last = lane;
     if (h->nlanes > 1) {
-        h->logl_cur = lane ^ 1;               // the next step runs on the other lane
+        h->logl_cur = (lane + 1) % h->nlanes; // the next step runs on the next lane
         if (!h->pipelined) { h->pipelined = true; h->geo_B = -1; }
     }
     return RVLL_OK;
@@ -955,8 +977,9 @@ int rvll_comm_destroy(rvll_handle* h)
     int rc = use_device(h);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(h->compute));
-    HIP_TRY(hipStreamSynchronize(h->lane1));
-    for (int lane = 1; lane >= 0; --lane) {
+    rc = sync_other_lanes(h);
+    if (rc) return rc;
+    for (int lane = kMaxLanes - 1; lane >= 0; --lane) {
         if (h->nccl_comm[lane] && g_rccl.lib) RCCL_TRY(g_rccl.CommDestroy(h->nccl_comm[lane]));
         h->nccl_comm[lane] = nullptr;
     }

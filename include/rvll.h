@@ -222,7 +222,7 @@ int rvll_dev_download(rvll_handle* h, int64_t B, double* theta /*or NULL*/,
 int rvll_dev_sync(rvll_handle* h);
 /* Device-resident launches run on one of two pipeline lanes (own stream, log-L and flags buffer each).  Flipping
  * the lane between independent batches keeps two launches in flight, so one batch's ramp-up hides the previous
- * one's tail; rvll_allgather_logl flips it by itself.  Returns the lane (0/1) the next launch will use.       */
+ * one's tail; rvll_allgather_logl advances it by itself.  Returns the lane the next launch will use.          */
 int rvll_dev_flip_lane(rvll_handle* h);
 /* Time `iters` log-L launches over the resident theta with HIP events on the
  * compute stream (after `warmup` untimed launches).                          */
