@@ -123,6 +123,22 @@ def cpu_baseline(w, layout, theta, gpu_logl, seconds):
     }, float(err.max()), float(iters.mean())
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner on STDOUT when a communicator is created; bench.py's stdout carries exactly one
+    JSON line, so file descriptor 1 points at stderr while the communicator is being set up."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def call_with_timeout(fn, seconds):
     """Run fn() in a daemon thread (the ctypes calls release the GIL) and give up after `seconds`: a stuck RCCL
     bootstrap must not hang the whole scaling run.  Returns (value, error)."""
@@ -179,7 +195,8 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist      # control plane only: barrier, max-reduce, id exchange
-        dist.init_process_group("gloo")
+        with stdout_to_stderr():              # gloo announces its connections on stdout
+            dist.init_process_group("gloo")
 
     w = make_workload(args.config)
     B = args.batch or (CONFIGS[args.config]["batch"] // (8 if args.config in (4, 5) else 1))
@@ -204,20 +221,21 @@ def main():
         # still completes and says so in `config.allgather`.
         ok, stuck = 1, False
         ids = [None]
-        if rank == 0:
-            uid, err = call_with_timeout(GpuRVModel.comm_unique_id, 120.0)
-            if err is not None:
-                ok, stuck = 0, isinstance(err, TimeoutError)
-                print(f"[rank {rank}] RCCL unavailable: {err}", file=sys.stderr)
-            ids = [uid]
-        dist.broadcast_object_list(ids, src=0)
-        if ok and ids[0] is not None:
-            _, err = call_with_timeout(lambda: model.comm_init(ids[0], world, rank), 180.0)
-            if err is not None:
-                ok, stuck = 0, stuck or isinstance(err, TimeoutError)
-                print(f"[rank {rank}] rvll_comm_init failed: {err}", file=sys.stderr)
-        else:
-            ok = 0
+        with stdout_to_stderr():
+            if rank == 0:
+                uid, err = call_with_timeout(GpuRVModel.comm_unique_id, 120.0)
+                if err is not None:
+                    ok, stuck = 0, isinstance(err, TimeoutError)
+                    print(f"[rank {rank}] RCCL unavailable: {err}", file=sys.stderr)
+                ids = [uid]
+            dist.broadcast_object_list(ids, src=0)
+            if ok and ids[0] is not None:
+                _, err = call_with_timeout(lambda: model.comm_init(ids[0], world, rank), 180.0)
+                if err is not None:
+                    ok, stuck = 0, stuck or isinstance(err, TimeoutError)
+                    print(f"[rank {rank}] rvll_comm_init failed: {err}", file=sys.stderr)
+            else:
+                ok = 0
         flag = torch.tensor([ok], dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         gather = "rccl" if int(flag.item()) == 1 else "gloo-host-fallback"
