@@ -254,7 +254,9 @@ int choose_points_per_block(rvll_handle* h, long long B)
         const size_t lds = lds_bytes_for(h, pb);
         if (pb > 1 && lds > 60 * 1024) break;
         const long long items = (long long)pb * Ne;
-        const double chunks = std::ceil((double)items / h->chunk_items);
+        // LDS windows hold whole points (or, beyond the window size, slices of one point)
+        const double chunks = Ne <= h->chunk_items ? std::ceil((double)pb / (h->chunk_items / Ne))
+                                                   : (double)pb * std::ceil((double)Ne / h->chunk_items);
         const double W = (double)((items + rvll::kWave - 1) / rvll::kWave) / 4.0 + 0.6 + 0.5 * (chunks - 1.0);
         const double blocks = std::ceil((double)B / pb);
         const int occ = rvll::loglike_blocks_per_cu(lds);

@@ -290,8 +290,11 @@ void loglike_kernel(const LoglikeArgs a)
     // 3. items: flattened (point, epoch) pairs of this block, CH at a time
     const ItemCtx cx{pp, ins, dr, lin, nfail, anyfail, jfail};
     const int nitems = npts * a.Ne;
-    for (int base = 0; base < nitems; base += a.CH) {
-        const int cend = min(base + a.CH, nitems);
+    // LDS windows are cut at point-local positions — whole points while a point fits the window, otherwise
+    // every point by itself at multiples of CH — so each point's sum has one order whatever the tiling
+    const int wpts = a.Ne <= a.CH ? a.CH / a.Ne : 0;
+    for (int base = 0, cend; base < nitems; base = cend) {
+        cend = wpts ? min(base + wpts * a.Ne, nitems) : min(base + a.CH, (base / a.Ne + 1) * a.Ne);
         for (int i = base + tid; i < cend; i += kThreads) {
             const int pl = i / a.Ne;
             const int j  = i - pl * a.Ne;

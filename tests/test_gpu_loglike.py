@@ -76,6 +76,21 @@ def test_result_independent_of_launch_geometry(gpu_required, pb):
     assert np.array_equal(got, base) or golden.rel_err(got, base).max() <= 1e-14
 
 
+@pytest.mark.parametrize("n_epochs, pbs", [(1000, (1, 3, 4, 5, 9)), (2000, (1, 2, 3, 5)), (4500, (1, 2, 3))])
+def test_result_independent_of_geometry_across_lds_windows(gpu_required, n_epochs, pbs):
+    """A tile larger than the LDS window is summed window by window; the windows are cut at point-local
+    positions, so the bits do not depend on how many points share a workgroup (nor on the shard size that
+    picked that number on a multi-GPU run)."""
+    rng = np.random.default_rng(n_epochs)
+    table, free, fixed, ranges, linpar = _synthetic_case(rng, n_epochs, 2, 2, False, 0, False)
+    theta = np.stack([rng.uniform(*ranges[nm], 301) for nm in free], axis=1)
+    with GpuRVModel(fixed, table, free) as m:
+        base = m.log_likelihood_batch(theta)
+        for pb in pbs:
+            m.set_points_per_block(pb)
+            assert np.array_equal(m.log_likelihood_batch(theta), base), pb
+
+
 def test_batch_of_one_and_scalar_callback(gpu_required):
     case = golden.config_case(3)
     with _model(case) as m:
