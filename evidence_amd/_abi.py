@@ -78,6 +78,12 @@ class Timing(C.Structure):
                 ("blocks", C.c_int32), ("threads", C.c_int32)]
 
 
+class FipTiming(C.Structure):
+    _fields_ = [("index_ms", C.c_double), ("accumulate_ms", C.c_double), ("rows", C.c_int64),
+                ("repeats", C.c_int32), ("reserved", C.c_int32)]
+
+
+FIP_MAX_PLANETS = 8
 Handle = C.c_void_p
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -108,6 +114,8 @@ PROTOTYPES = {
     "rvll_download_gathered": (C.c_int, [Handle, C.c_int64, _dp]),
     "rvll_comm_destroy": (C.c_int, [Handle]),
     "rvll_kep_rv_batch": (C.c_int, [Handle, _dp, C.c_int64, _dp, C.c_int32, C.c_uint32, _dp]),
+    "rvll_fip_accumulate": (C.c_int, [C.c_int32, _dp, _dp, C.c_int32, _dp, _dp, C.POINTER(C.c_int64), C.c_int32,
+                                      C.c_int32, _dp, C.c_int32, C.POINTER(FipTiming)]),
     "rvll_debug_eval": (C.c_int, [Handle, C.c_int32, _dp, _dp, C.c_int64, _dp]),
     "rvll_last_error": (C.c_char_p, []),
     "rvll_version": (C.c_int, [_ip, _ip]),

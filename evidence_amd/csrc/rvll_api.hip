@@ -36,6 +36,24 @@ int fail(int code, const char* fmt, ...)
     return code;
 }
 
+}  // namespace
+
+// error reporting for the other translation units of the library (rvll_fip.hip)
+namespace rvll {
+int report_error(int code, const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+}  // namespace rvll
+
+namespace {
+
 #define HIP_TRY(expr)                                                               \
     do {                                                                            \
         hipError_t e_ = (expr);                                                     \

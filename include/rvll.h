@@ -257,6 +257,30 @@ int rvll_comm_destroy(rvll_handle* h);
 int rvll_kep_rv_batch(rvll_handle* h, const double* theta, int64_t B, const double* times,
                       int32_t n_times, uint32_t include_mask, double* out /*[B, n_times]*/);
 
+/* ---- FIP periodogram accumulation (post-processing; independent of any model handle) ------------ */
+/* Replaces the accumulation loop of evidence/fip_criterion.py:305-339.  The caller flattens the posterior
+ * samples of all planet models of one run into rows, in the reference's loop order (kmod = 1.., then sample
+ * i), NaN-padding each row to np_max periods, with contrib[row] = pky[kmod] * weights[i] / sum(weights)
+ * (:315, :339); rows of run r are run_start[r] .. run_start[r+1].  nua/nub are the window edges
+ * nu -/+ nu_window/2 of :233-236 (ascending).  For every row and period x:  f = 2*pi/x,
+ * beg = searchsorted(nub, f, 'right'), end = searchsorted(nua, f, 'left'); every bin in the UNION of the
+ * row's [beg, end) ranges gets fapnu[r][bin] -= contrib[row], in row order (numpy's fancy-index `-=` applies
+ * a repeated index once).  fapnu is [n_runs, nfreq], in/out (the reference starts from ones, :307); the
+ * result is bit-identical to the reference's loop.  `repeats` > 1 re-runs the two kernels from the same
+ * input for timing; timing may be NULL.  device < 0 uses the current device.                            */
+#define RVLL_FIP_MAX_PLANETS 8
+typedef struct rvll_fip_timing {
+    double  index_ms;        /* mean HIP-event time of the interval (searchsorted) kernel   */
+    double  accumulate_ms;   /* mean HIP-event time of the ordered fold kernel              */
+    int64_t rows;
+    int32_t repeats;
+    int32_t reserved;
+} rvll_fip_timing;
+int rvll_fip_accumulate(int32_t device, const double* nua, const double* nub, int32_t nfreq,
+                        const double* periods /*[rows, np_max]*/, const double* contrib /*[rows]*/,
+                        const int64_t* run_start /*[n_runs + 1]*/, int32_t n_runs, int32_t np_max,
+                        double* fapnu /*[n_runs, nfreq] in/out*/, int32_t repeats, rvll_fip_timing* timing);
+
 /* ---- diagnostics -------------------------------------------------------------- */
 /* Evaluate one device math routine elementwise (tests only; no reference counterpart):
  * op 0 sin, 1 cos (rvll sincos), 2 div_exact(x,y), 3 x/y (IEEE), 4 div_fast(x,y),

@@ -45,6 +45,8 @@ def load():
         lib.rvo_max_threads.restype = C.c_int
         lib.rvo_kep_rv_batch.restype = C.c_int
         lib.rvo_kep_rv_batch.argtypes = [C.POINTER(_abi.Layout), _dp, C.c_long, _dp, C.c_int, C.c_uint, _dp]
+        lib.rvo_fip_accumulate.argtypes = [_dp, _dp, C.c_int, _dp, _dp, C.c_long, C.c_int, _dp]
+        lib.rvo_fip_accumulate.restype = C.c_int
         _lib = lib
     return _lib
 
@@ -125,3 +127,24 @@ class OracleModel:
 
 def max_threads():
     return int(load().rvo_max_threads())
+
+
+def fip_accumulate(nua, nub, periods, contrib, run_start):
+    """The C fold of rvo_fip_accumulate, run by run: fapnu [R, nfreq] starting from ones."""
+    lib = load()
+    nua = np.ascontiguousarray(nua, dtype=np.float64)
+    nub = np.ascontiguousarray(nub, dtype=np.float64)
+    periods = np.ascontiguousarray(periods, dtype=np.float64)
+    contrib = np.ascontiguousarray(contrib, dtype=np.float64)
+    fapnu = np.ones((len(run_start) - 1, nua.size))
+    for r in range(len(run_start) - 1):
+        lo, hi = int(run_start[r]), int(run_start[r + 1])
+        row = fapnu[r]
+        p = np.ascontiguousarray(periods[lo:hi])
+        c = np.ascontiguousarray(contrib[lo:hi])
+        rc = lib.rvo_fip_accumulate(nua.ctypes.data_as(_dp), nub.ctypes.data_as(_dp), nua.size,
+                                    p.ctypes.data_as(_dp), c.ctypes.data_as(_dp), hi - lo, periods.shape[1],
+                                    row.ctypes.data_as(_dp))
+        if rc:
+            raise RuntimeError("rvo_fip_accumulate failed")
+    return fapnu

@@ -308,6 +308,46 @@ RVO_EXPORT int rvo_kep_rv_batch(const rvll_layout* L, const double* theta, long 
     return 0;
 }
 
+/* FIP periodogram accumulation, restating evidence/fip_criterion.py:319-339 for ONE run: rows are the
+ * posterior samples of all planet models in loop order, periods NaN-padded to np_max, contrib[row] =
+ * pky[k]*w_i.  Per row: f = 2*pi/x (:321), beg = searchsorted(nub, f, 'right') (:334), end =
+ * searchsorted(nua, f, 'left') (:335), and every bin of the UNION of the [beg, end) ranges gets
+ * fapnu[bin] -= contrib[row] once (:339: a repeated fancy index is applied once), rows in order.      */
+static int fip_count_le(const double* a, int n, double v)
+{
+    int lo = 0, hi = n;
+    if (v != v) return n;                        /* numpy sorts NaN last */
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (a[mid] <= v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+static int fip_count_lt(const double* a, int n, double v)
+{
+    int lo = 0, hi = n;
+    if (v != v) return n;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (a[mid] < v) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+RVO_EXPORT int rvo_fip_accumulate(const double* nua, const double* nub, int nfreq, const double* periods,
+                                  const double* contrib, long n_rows, int np_max, double* fapnu)
+{
+    int beg[16], end[16];
+    if (np_max < 1 || np_max > 16) return -1;
+    for (long r = 0; r < n_rows; ++r) {
+        for (int j = 0; j < np_max; ++j) {
+            const double f = 2 * M_PI / periods[(size_t)r * np_max + j];
+            beg[j] = fip_count_le(nub, nfreq, f);
+            end[j] = fip_count_lt(nua, nfreq, f);
+        }
+        for (int j = 0; j < np_max; ++j)
+            for (int b = beg[j]; b < end[j]; ++b) {
+                int seen = 0;
+                for (int q = 0; q < j && !seen; ++q) seen = b >= beg[q] && b < end[q];
+                if (!seen) fapnu[b] -= contrib[r];
+            }
+    }
+    return 0;
+}
+
 RVO_EXPORT int rvo_max_threads(void)
 {
 #ifdef _OPENMP
