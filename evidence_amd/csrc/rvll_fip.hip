@@ -12,13 +12,11 @@
 // Mapping: the host flattens (k, i) into rows in the reference's loop order with c = pky[k]*weights[i].
 //   fip_index_kernel       one thread per (row, planet): IEEE division, two binary searches on the caller's
 //                          own nua/nub arrays (index work — exactly numpy's answer), intervals stored SoA.
-//   fip_accumulate_kernel  one thread per (run, bin); a workgroup owns 256 consecutive bins of one run and
-//                          streams that run's rows 256 at a time: each thread tests one row against the
-//                          tile, the hits are compacted IN ROW ORDER into LDS (ballot + prefix), then every
-//                          thread folds the hits that cover its bin.  No atomics, no sort: the fold order is
-//                          the reference's, the result is bit-identical and run-to-run deterministic.
-// Integer/HBM-side work: per tile the rows are re-read from L2 (n_rows * (8 + 8*np) bytes); the intervals
-// of one posterior are a few MB and stay cache-resident.
+//   fip_accumulate_kernel  one thread per (run, bin); see the comment at the kernel.  No atomics, no sort: the
+//                          fold order is the reference's, the result is bit-identical and deterministic.
+// Integer / cache-side work around a strictly sequential fp64 chain per bin: every tile re-reads its run's
+// spans from L2 (rows * 8 * np bytes, a few MB per posterior, cache-resident); the time is set by the hottest
+// bin — a posterior peak receives most of the samples — at ~7 vector instructions per covering sample.
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
@@ -38,6 +36,8 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kWave = 64;
 constexpr int kMaxPlanets = RVLL_FIP_MAX_PLANETS;
+constexpr int kRowsPerThread = 2;
+constexpr int kDenseHits = 16;          // rows of a 64-row group that must touch a wave for the straight-line path
 
 #define FIP_TRY(expr)                                                                          \
     do {                                                                                       \
@@ -91,15 +91,87 @@ void fip_index_kernel(const double* __restrict__ periods, long long n_rows, int 
     }
 }
 
+// coverage of the 64 bins [lo, lo + 64) by the span [beg, end), one bit per bin
+__device__ __forceinline__ unsigned long long span_bits(int2 sp, int lo)
+{
+    const int a = max(sp.x - lo, 0), b = min(sp.y - lo, kWave);
+    if (a >= b) return 0ull;
+    const unsigned long long upto_b = b >= kWave ? ~0ull : ((1ull << b) - 1ull);
+    return upto_b & ~((1ull << a) - 1ull);
+}
+
+__device__ __forceinline__ unsigned long long lane_u64(unsigned long long x, int h)
+{
+    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)x, h);
+    const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(x >> 32), h);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// v -= c in the lanes whose bit is set in the wave-uniform mask m (a scalar register pair; c is the same in
+// every lane): one v_add_f64 under a narrowed EXEC instead of an add plus two v_cndmask
+__device__ __forceinline__ void masked_sub(double& v, unsigned long long m, double c)
+{
+    unsigned long long saved;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 "s_and_b64 exec, %[sv], %[m]\n\t"
+                 "v_add_f64 %[v], %[v], -%[c]\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [v] "+v"(v), [sv] "=&s"(saved)
+                 : [m] "s"(m), [c] "v"(c)
+                 : "scc");
+}
+
+// four of them back to back (rows h .. h+3 in order): the sixteen v_readlane of the batch issue ahead of the
+// dependent add chain, and EXEC is saved and restored once
+__device__ __forceinline__ void masked_sub4(double& v, unsigned long long m0, double c0, unsigned long long m1,
+                                            double c1, unsigned long long m2, double c2, unsigned long long m3,
+                                            double c3)
+{
+    unsigned long long saved;
+    asm volatile("s_mov_b64 %[sv], exec\n\t"
+                 "s_and_b64 exec, %[sv], %[m0]\n\t"
+                 "v_add_f64 %[v], %[v], -%[c0]\n\t"
+                 "s_and_b64 exec, %[sv], %[m1]\n\t"
+                 "v_add_f64 %[v], %[v], -%[c1]\n\t"
+                 "s_and_b64 exec, %[sv], %[m2]\n\t"
+                 "v_add_f64 %[v], %[v], -%[c2]\n\t"
+                 "s_and_b64 exec, %[sv], %[m3]\n\t"
+                 "v_add_f64 %[v], %[v], -%[c3]\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [v] "+v"(v), [sv] "=&s"(saved)
+                 : [m0] "s"(m0), [c0] "v"(c0), [m1] "s"(m1), [c1] "v"(c1), [m2] "s"(m2), [c2] "v"(c2),
+                   [m3] "s"(m3), [c3] "v"(c3)
+                 : "scc");
+}
+
+// Workgroup barrier that only waits for this wave's LDS traffic: the global loads prefetching the next chunk
+// stay in flight across it (a full __syncthreads would drain them first).
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// A workgroup owns 256 consecutive bins of one run (wave w: bins tile_lo + 64 w ..) and streams the run's rows
+// kRowsPerThread * 256 at a time.  Phase 1, one thread per row: the union of the row's spans becomes one 64-bit
+// coverage mask per wave (index work, vectorised over rows) and goes to LDS with the row's contribution; the
+// spans of the NEXT chunk are requested before that, so their latency hides behind phase 2.  Phase 2, per wave:
+// the rows with a non-zero mask are visited in row order; the mask of the visited row is moved to a scalar
+// register pair (v_readlane), its contribution is an LDS broadcast, and the subtraction runs under EXEC = mask,
+// which is bit-identical to skipping it in the uncovered lanes.  Groups of 64 rows that mostly touch the wave
+// take a straight-line path over all 64 (an empty mask changes nothing); sparse groups walk the set bits.
+// The LDS stage is double-buffered, so one barrier per chunk suffices.  The per-bin fold stays strictly
+// sequential; its cost is ~3 vector instructions per (row, wave) the row touches.
 template <int NP>
 __global__ __launch_bounds__(kThreads)
 void fip_accumulate_kernel(const int2* __restrict__ spans, const double* __restrict__ contrib,
                            const long long* __restrict__ run_start, long long n_rows, int nfreq,
                            double* __restrict__ fapnu)
 {
-    __shared__ int2   hit_span[NP][kThreads];
-    __shared__ double hit_c[kThreads];
-    __shared__ int    wave_hits[kThreads / kWave];
+    constexpr int kWaves = kThreads / kWave;
+    constexpr int kChunk = kThreads * kRowsPerThread;
+    __shared__ unsigned long long s_mask[2][kWaves][kChunk];
+    __shared__ double s_c[2][kChunk];
+    __shared__ int s_any[2][kWaves];
 
     const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
     const int run = blockIdx.y;
@@ -109,44 +181,88 @@ void fip_accumulate_kernel(const int2* __restrict__ spans, const double* __restr
     const long long r0 = run_start[run], r1 = run_start[run + 1];
     double v = bin < nfreq ? fapnu[(long long)run * nfreq + bin] : 0.;
 
-    for (long long base = r0; base < r1; base += kThreads) {
-        const long long row = base + tid;
-        int2 sp[NP];
-        bool hit = false;
-        double c = 0.;
-        if (row < r1) {
+    int2 sp_next[kRowsPerThread][NP];
+    double c_next[kRowsPerThread];
+    auto fetch = [&](long long base) {
 #pragma unroll
-            for (int j = 0; j < NP; ++j) {
-                sp[j] = spans[(long long)j * n_rows + row];
-                hit |= sp[j].x < sp[j].y && sp[j].x < tile_hi && sp[j].y > tile_lo;
+        for (int q = 0; q < kRowsPerThread; ++q) {
+            const long long row = base + tid + q * kThreads;
+            const bool ok = row < r1;
+#pragma unroll
+            for (int j = 0; j < NP; ++j) sp_next[q][j] = ok ? spans[(long long)j * n_rows + row] : make_int2(0, 0);
+            c_next[q] = ok ? contrib[row] : 0.;
+        }
+    };
+    fetch(r0);
+
+    int buf = 0;
+    for (long long base = r0; base < r1; base += kChunk, buf ^= 1) {
+        int2 sp[kRowsPerThread][NP];
+        double c[kRowsPerThread];
+#pragma unroll
+        for (int q = 0; q < kRowsPerThread; ++q) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) sp[q][j] = sp_next[q][j];
+            c[q] = c_next[q];
+        }
+        if (base + kChunk < r1) fetch(base + kChunk);
+
+        // phase 1
+        bool any = false;
+#pragma unroll
+        for (int q = 0; q < kRowsPerThread; ++q) {
+            unsigned long long m[kWaves];
+#pragma unroll
+            for (int w = 0; w < kWaves; ++w) m[w] = 0ull;
+            bool hit = false;
+#pragma unroll
+            for (int j = 0; j < NP; ++j)
+                hit |= sp[q][j].x < sp[q][j].y && sp[q][j].x < tile_hi && sp[q][j].y > tile_lo;
+            if (hit) {
+#pragma unroll
+                for (int j = 0; j < NP; ++j)
+#pragma unroll
+                    for (int w = 0; w < kWaves; ++w) m[w] |= span_bits(sp[q][j], tile_lo + w * kWave);
+                any = true;
             }
-            if (hit) c = contrib[row];
-        }
-        // ordered compaction of the hits: position = hits in earlier waves + hits in lower lanes
-        const unsigned long long mask = __ballot(hit);
-        if (lane == 0) wave_hits[wave] = __popcll(mask);
-        __syncthreads();
-        int before = 0, total = 0;
 #pragma unroll
-        for (int w = 0; w < kThreads / kWave; ++w) {
-            const int h = wave_hits[w];
-            if (w < wave) before += h;
-            total += h;
+            for (int w = 0; w < kWaves; ++w) s_mask[buf][w][tid + q * kThreads] = m[w];
+            s_c[buf][tid + q * kThreads] = c[q];
         }
-        if (hit) {
-            const int pos = before + __popcll(mask & ((1ull << lane) - 1ull));
+        const unsigned long long wave_any = __ballot(any);
+        if (lane == 0) s_any[buf][wave] = wave_any != 0ull;
+        lds_barrier();
+        if (!(s_any[buf][0] | s_any[buf][1] | s_any[buf][2] | s_any[buf][3])) continue;   // no row touches this tile
+
+        // phase 2
+        for (int g = 0; g < kChunk / kWave; ++g) {
+            const unsigned long long mv = s_mask[buf][wave][g * kWave + lane];
+            const double* cg = &s_c[buf][g * kWave];
+            unsigned long long todo = __ballot(mv != 0ull);
+            if (__popcll(todo) >= kDenseHits) {
+                double cn[8];                           // contributions are fetched two batches ahead of their use
 #pragma unroll
-            for (int j = 0; j < NP; ++j) hit_span[j][pos] = sp[j];
-            hit_c[pos] = c;
-        }
-        __syncthreads();
-        for (int h = 0; h < total; ++h) {
-            bool covered = false;
+                for (int i = 0; i < 8; ++i) cn[i] = cg[i];
 #pragma unroll
-            for (int j = 0; j < NP; ++j) covered |= bin >= hit_span[j][h].x && bin < hit_span[j][h].y;
-            if (covered) v -= hit_c[h];
+                for (int h = 0; h < kWave; h += 4) {
+                    const double c0 = cn[0], c1 = cn[1], c2 = cn[2], c3 = cn[3];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) cn[i] = cn[i + 4];
+                    if (h + 8 < kWave) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) cn[4 + i] = cg[h + 8 + i];
+                    }
+                    masked_sub4(v, lane_u64(mv, h), c0, lane_u64(mv, h + 1), c1, lane_u64(mv, h + 2), c2,
+                                lane_u64(mv, h + 3), c3);
+                }
+            } else {
+                while (todo) {
+                    const int h = __builtin_ctzll(todo);
+                    todo &= todo - 1ull;
+                    masked_sub(v, lane_u64(mv, h), cg[h]);
+                }
+            }
         }
-        __syncthreads();
     }
     if (bin < nfreq) fapnu[(long long)run * nfreq + bin] = v;
 }

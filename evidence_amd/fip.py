@@ -52,7 +52,7 @@ def flatten_posteriors(posteriors, pky):
                  default=1)
     if np_max > _abi.FIP_MAX_PLANETS:
         raise ValueError(f"more than {_abi.FIP_MAX_PLANETS} periods per sample")
-    blocks, contribs, run_start = [], [], [0]
+    entries, run_start, rows = [], [0], 0
     for per_k in posteriors:
         for kmod in range(1, len(per_k)):
             if per_k[kmod] is None:
@@ -60,17 +60,19 @@ def flatten_posteriors(posteriors, pky):
             samples, weights = per_k[kmod]
             samples = np.asarray(samples, dtype=np.float64)
             samples = samples.reshape(len(samples), -1)
-            weights = np.array(weights, dtype=np.float64)
             if len(weights) != len(samples):
                 raise ValueError("one weight per sample required")
-            weights /= np.sum(weights)                                        # :315
-            block = np.full((len(samples), np_max), np.nan)
-            block[:, : samples.shape[1]] = samples
-            blocks.append(block)
-            contribs.append(pky[kmod] * weights)                              # :339
-        run_start.append(sum(len(b) for b in blocks))
-    periods = np.ascontiguousarray(np.concatenate(blocks)) if blocks else np.empty((0, np_max))
-    contrib = np.ascontiguousarray(np.concatenate(contribs)) if contribs else np.empty(0)
+            entries.append((rows, kmod, samples, weights))
+            rows += len(samples)
+        run_start.append(rows)
+    periods = np.empty((rows, np_max))
+    contrib = np.empty(rows)
+    for lo, kmod, samples, weights in entries:
+        hi, k = lo + len(samples), samples.shape[1]
+        periods[lo:hi, :k] = samples
+        periods[lo:hi, k:] = np.nan
+        np.divide(weights, np.sum(weights), out=contrib[lo:hi])              # :315  weights /= np.sum(weights)
+        np.multiply(pky[kmod], contrib[lo:hi], out=contrib[lo:hi])            # :339  pky[kmod]*weights[i]
     return periods, contrib, np.asarray(run_start, dtype=np.int64)
 
 
