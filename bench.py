@@ -182,6 +182,32 @@ def pmc_traffic(cfg, batch):
     return (2.0 * rec["fetch_kib"] + rec["write_kib"]) * 1024.0
 
 
+def fip_extra(with_cpu):
+    """SURVEY §8 f4 (never `value`): the FIP periodogram accumulation of fip_criterion.py:305-339 on synthetic
+    posteriors (3 runs x 3 planet models x 30 000 samples, the script's 50 000 bins) — HIP-event kernel times,
+    and the oracle's C fold of the same rows on one host core as the checker and CPU baseline."""
+    from evidence_amd import fip
+    rng = np.random.default_rng(2021)
+    pmin, pmax, tobs, n = 1.5, 1000.0, 1000.0, 30000
+    peaks = np.exp(rng.uniform(np.log(pmin * 2), np.log(pmax / 2), 3))
+    post = [[None] + [(np.where(rng.random((n, k)) < 0.8, peaks[:k] * np.exp(rng.normal(0, 5e-4, (n, k))),
+                                np.exp(rng.uniform(np.log(pmin), np.log(pmax), (n, k)))), rng.gamma(0.5, 1.0, n))
+                      for k in (1, 2, 3)] for _ in range(3)]
+    pky = rng.dirichlet(np.ones(4))
+    _, nua, nub = fip.frequency_grid(pmin, pmax, tobs)
+    got, t = fip.fip_periodogram(post, pky, nua, nub, repeats=10, return_timing=True)
+    res = {"rows": int(t["rows"]), "bins": int(nua.size), "index_kernel_ms": t["index_ms"],
+           "accumulate_kernel_ms": t["accumulate_ms"], "rows_per_s": t["rows"] / (t["index_ms"] + t["accumulate_ms"]) * 1e3}
+    if with_cpu:
+        from oracle import oracle          # checker + CPU baseline leg only
+        periods, contrib, run_start = fip.flatten_posteriors(post, pky)
+        t0 = time.perf_counter()
+        want = oracle.fip_accumulate(nua, nub, periods, contrib, run_start)
+        res["cpu_fold_ms_1core"] = (time.perf_counter() - t0) * 1e3
+        res["bit_identical_to_oracle"] = bool(np.array_equal(got, want))
+    return res
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -341,6 +367,7 @@ def main():
             model.dev_sync()
             out["prior_plus_loglike_evals_per_s"] = 50 * B / (time.perf_counter() - t1)
             model.dev_upload_theta(theta)
+            out["fip_periodogram"] = fip_extra(not args.no_cpu)
         if not args.no_cpu and world == 1:
             cpu, perr, mean_it = cpu_baseline(w, model.layout, theta, gpu_logl, args.cpu_seconds)
             out["cpu_baseline"] = cpu
