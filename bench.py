@@ -366,6 +366,14 @@ def main():
                 model.dev_prior(B); model.dev_loglike(B)
             model.dev_sync()
             out["prior_plus_loglike_evals_per_s"] = 50 * B / (time.perf_counter() - t1)
+            for _ in range(5):
+                model.dev_prior_loglike(B)
+            model.dev_sync()
+            t1 = time.perf_counter()
+            for _ in range(50):
+                model.dev_prior_loglike(B)
+            model.dev_sync()
+            out["prior_plus_loglike_one_launch_evals_per_s"] = 50 * B / (time.perf_counter() - t1)
             model.dev_upload_theta(theta)
             out["fip_periodogram"] = fip_extra(not args.no_cpu)
         if not args.no_cpu and world == 1:

@@ -94,6 +94,7 @@ PROTOTYPES = {
                               C.POINTER(Handle)]),
     "rvll_destroy": (C.c_int, [Handle]),
     "rvll_set_priors": (C.c_int, [Handle, C.POINTER(Prior), C.c_int32]),
+    "rvll_prior_table_info": (C.c_int, [Handle, C.c_int32, _dp, _ip]),
     "rvll_loglike_batch": (C.c_int, [Handle, _dp, C.c_int64, _dp, _ip]),
     "rvll_prior_batch": (C.c_int, [Handle, _dp, C.c_int64, _dp]),
     "rvll_prior_loglike_batch": (C.c_int, [Handle, _dp, C.c_int64, _dp, _dp, _ip]),
@@ -103,6 +104,7 @@ PROTOTYPES = {
     "rvll_dev_fill_cube": (C.c_int, [Handle, C.c_int64, C.c_uint64]),
     "rvll_dev_prior": (C.c_int, [Handle, C.c_int64]),
     "rvll_dev_loglike": (C.c_int, [Handle, C.c_int64]),
+    "rvll_dev_prior_loglike": (C.c_int, [Handle, C.c_int64]),
     "rvll_dev_download": (C.c_int, [Handle, C.c_int64, _dp, _dp, _ip]),
     "rvll_dev_sync": (C.c_int, [Handle]),
     "rvll_dev_flip_lane": (C.c_int, [Handle]),

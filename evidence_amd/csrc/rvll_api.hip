@@ -115,6 +115,7 @@ void dev_free(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
 }  // namespace
 
 constexpr int kMaxLanes = 4;
+constexpr long long kFusedMaxPoints = 4096;   // rvll_prior_loglike_batch: one launch up to here, two beyond
 
 struct rvll_handle {
     int device = 0;
@@ -146,6 +147,8 @@ struct rvll_handle {
     int32_t* d_heavy = nullptr;
     int n_heavy = 0;
     std::vector<double*> d_tables;
+    std::vector<double> table_err;              // measured quintic-interpolant error per parameter (NaN: no table)
+    std::vector<int> table_direct;              // per parameter: evaluated by verified interpolation alone
 
     // batch buffers
     long long cap = 0;
@@ -324,6 +327,16 @@ int build_args(rvll_handle* h, const double* d_theta, double* d_logL, int32_t* d
     return RVLL_OK;
 }
 
+// fused cube -> theta -> log-L launch: the same arguments plus the prior table and the two row buffers
+void make_fused(const rvll_handle* h, const double* d_cube, double* d_theta_out, rvll::LoglikeArgs* a)
+{
+    a->cube = d_cube;
+    a->theta_out = d_theta_out;
+    a->priors = h->d_priors;
+    a->heavy_dims = h->d_heavy;
+    a->n_heavy = h->n_heavy;
+}
+
 int ensure_capacity(rvll_handle* h, long long B)
 {
     if (B <= h->cap) return RVLL_OK;
@@ -348,6 +361,8 @@ void free_priors(rvll_handle* h)
 {
     for (double*& p : h->d_tables) dev_free(p);
     h->d_tables.clear();
+    h->table_err.clear();
+    h->table_direct.clear();
     dev_free(h->d_priors);
     dev_free(h->d_heavy);
     h->n_heavy = 0;
@@ -532,17 +547,30 @@ int rvll_set_priors(rvll_handle* h, const rvll_prior* priors, int32_t ndim)
     }
     free_priors(h);
     std::vector<rvll_prior> dev(priors, priors + ndim);
+    h->table_err.assign((size_t)ndim, NAN);
+    h->table_direct.assign((size_t)ndim, 0);
     for (int d = 0; d < ndim; ++d) {
         if (dev[d].kind == RVLL_PRIOR_BETA || dev[d].kind == RVLL_PRIOR_GAMMA) {
             // the device tabulates this prior's quantile function once; the kernel starts from it
+            // (nodes: value, slope, second derivative) and measures its own quintic interpolant against the
+            // full solver; a verified table is evaluated by interpolation alone (table_post = 1)
             const size_t nb = sizeof(double) * (size_t)rvll::prior_table_nodes();
-            double *dz0 = nullptr, *dz1 = nullptr;
+            double *dz0 = nullptr, *dz1 = nullptr, *derr = nullptr;
             HIP_TRY(hipMalloc(&dz0, nb)); h->d_tables.push_back(dz0);
-            HIP_TRY(hipMalloc(&dz1, nb)); h->d_tables.push_back(dz1);
-            HIP_TRY(rvll::launch_prior_table(dev[d].kind, priors[d].args, dz0, dz1, h->compute));
+            HIP_TRY(hipMalloc(&dz1, 2 * nb)); h->d_tables.push_back(dz1);
+            HIP_TRY(hipMalloc(&derr, sizeof(double))); h->d_tables.push_back(derr);
+            HIP_TRY(hipMemsetAsync(derr, 0, sizeof(double), h->compute));
+            HIP_TRY(rvll::launch_prior_table(dev[d].kind, priors[d].args, dz0, dz1,
+                                             reinterpret_cast<unsigned long long*>(derr), h->compute));
+            double err = INFINITY;
+            HIP_TRY(hipMemcpyAsync(&err, derr, sizeof(double), hipMemcpyDeviceToHost, h->compute));
+            HIP_TRY(hipStreamSynchronize(h->compute));
             dev[d].table_cdf = dz0;
             dev[d].table_x = dz1;
             dev[d].table_n = rvll::prior_table_nodes();
+            dev[d].table_post = (err <= rvll::prior_table_direct_tol() && !getenv("RVLL_NO_DIRECT_TABLES")) ? 1 : 0;
+            h->table_err[(size_t)d] = err;
+            h->table_direct[(size_t)d] = dev[d].table_post;
             continue;
         }
         if (dev[d].kind != RVLL_PRIOR_TABLE) { dev[d].table_cdf = dev[d].table_x = nullptr; continue; }
@@ -567,6 +595,16 @@ int rvll_set_priors(rvll_handle* h, const rvll_prior* priors, int32_t ndim)
     h->n_heavy = (int)heavy.size();
     HIP_TRY(hipStreamSynchronize(h->compute));          // start tables are built
     h->have_priors = true;
+    return RVLL_OK;
+}
+
+int rvll_prior_table_info(rvll_handle* h, int32_t dim, double* max_err, int32_t* direct)
+{
+    if (!h) return fail(RVLL_E_INVALID, "null handle");
+    if (!h->have_priors) return fail(RVLL_E_NOPRIORS, "rvll_set_priors has not been called");
+    if (dim < 0 || dim >= (int32_t)h->table_err.size()) return fail(RVLL_E_INVALID, "dim %d out of range", dim);
+    if (max_err) *max_err = h->table_err[(size_t)dim];
+    if (direct) *direct = h->table_direct[(size_t)dim];
     return RVLL_OK;
 }
 
@@ -660,6 +698,25 @@ int rvll_dev_loglike(rvll_handle* h, int64_t B)
     if (rc) return rc;
     HIP_TRY(rvll::launch_loglike(a, lane_stream(h, lane)));
     h->logl_last = lane;
+    return RVLL_OK;
+}
+
+int rvll_dev_prior_loglike(rvll_handle* h, int64_t B)
+{
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!h->have_priors) return fail(RVLL_E_NOPRIORS, "rvll_set_priors has not been called");
+    if (B < 0 || B > h->cap) return fail(RVLL_E_INVALID, "B %lld outside reserved capacity %lld", (long long)B, h->cap);
+    if (B == 0) return RVLL_OK;
+    rc = sync_other_lanes(h);                  // theta is rewritten: no other lane may still be reading it
+    if (rc) return rc;
+    rvll::LoglikeArgs a;
+    rc = build_args(h, h->d_theta, h->d_logL2[0], h->d_flags2[0], B, &a);
+    if (rc) return rc;
+    make_fused(h, h->d_cube, h->d_theta, &a);
+    HIP_TRY(rvll::launch_prior_loglike(a, h->compute));
+    h->theta_async = true;
+    h->logl_last = 0;
     return RVLL_OK;
 }
 
@@ -819,22 +876,22 @@ int rvll_prior_loglike_batch(rvll_handle* h, const double* cube, int64_t B,
     const size_t nin = sizeof(double) * (size_t)B * (size_t)h->L.ndim;
     const size_t nout = (sizeof(double) + sizeof(int32_t)) * (size_t)B;
     if (nin <= 64 * 1024 && nout <= 64 * 1024) {
-        // small batch (a sampler's proposal round): the prior kernels read the cube from mapped pinned host
-        // memory, theta stays in HBM for the log-L kernel, log-L and flags are written back zero-copy; theta
-        // returns with one copy command into the same pinned block
+        // small batch (a sampler's proposal round): the fused kernel reads the cube from mapped pinned host
+        // memory, theta goes to HBM, log-L and flags are written back zero-copy; theta returns with one copy
+        // command into the same pinned block
         int rc = rvll_dev_reserve(h, B);
         if (rc) return rc;
         HIP_TRY(hipStreamSynchronize(h->compute));
         memcpy(h->pin_in, cube, nin);
-        rvll::PriorArgs pa{static_cast<const double*>(h->pin_in_dev), h->d_theta, (long long)B, h->L.ndim,
-                           h->d_priors, h->d_heavy, h->n_heavy};
-        HIP_TRY(rvll::launch_prior(pa, h->compute));
+        rc = sync_other_lanes(h);
+        if (rc) return rc;
         double* out_l = static_cast<double*>(h->pin_out_dev);
         int32_t* out_f = reinterpret_cast<int32_t*>(out_l + B);
         rvll::LoglikeArgs a;
         rc = build_args(h, h->d_theta, out_l, out_f, B, &a);
         if (rc) return rc;
-        HIP_TRY(rvll::launch_loglike(a, h->compute));
+        make_fused(h, static_cast<const double*>(h->pin_in_dev), h->d_theta, &a);
+        HIP_TRY(rvll::launch_prior_loglike(a, h->compute));
         char* host_out = static_cast<char*>(h->pin_out);
         if (theta_out) HIP_TRY(hipMemcpyAsync(host_out + nout, h->d_theta, nin, hipMemcpyDeviceToHost, h->compute));
         HIP_TRY(hipStreamSynchronize(h->compute));
@@ -845,10 +902,18 @@ int rvll_prior_loglike_batch(rvll_handle* h, const double* cube, int64_t B,
     }
     int rc = rvll_dev_upload_cube(h, cube, B);
     if (rc) return rc;
-    rc = rvll_dev_prior(h, B);
-    if (rc) return rc;
-    rc = rvll_dev_loglike(h, B);
-    if (rc) return rc;
+    // measured (profiles/r01_fused_probe.txt): one launch saves ~1 us up to a few thousand points; beyond that
+    // the separate prior kernels win by ~5 % because their work spreads over the whole chip instead of
+    // running as a short serial prologue of every log-L workgroup
+    if (B <= kFusedMaxPoints) {
+        rc = rvll_dev_prior_loglike(h, B);
+        if (rc) return rc;
+    } else {
+        rc = rvll_dev_prior(h, B);
+        if (rc) return rc;
+        rc = rvll_dev_loglike(h, B);
+        if (rc) return rc;
+    }
     return rvll_dev_download(h, B, theta_out, logL, flags);
 }
 

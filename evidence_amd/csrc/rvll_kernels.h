@@ -41,6 +41,12 @@ struct LoglikeArgs {
     int    PB;               // live points per workgroup
     int    CH;               // contribution slots in LDS (items per chunk)
     double cte;              // -0.5 * Ne * log(2*pi)
+    // fused cube -> theta -> log-L form (launch_prior_loglike): the staging step applies the prior transform
+    const double*      cube;        // [B, D] unit-cube rows, or nullptr for the plain form
+    double*            theta_out;   // [B, D] the transformed parameters are also written here
+    const rvll_prior*  priors;      // [D]
+    const int32_t*     heavy_dims;  // [n_heavy] parameters with an iterative quantile (Beta, Gamma)
+    int                n_heavy;
 };
 
 size_t loglike_lds_bytes(const LoglikeArgs& a);
@@ -58,9 +64,15 @@ struct PriorArgs {
     int           n_heavy;
 };
 hipError_t launch_prior(const PriorArgs& a, hipStream_t stream);
-// device-built start table of a Beta/Gamma prior: z[n], dz[n] with n = prior_table_nodes()
+// one launch: prior transform in the staging step of the log-L kernel (a.cube / theta_out / priors set)
+hipError_t launch_prior_loglike(const LoglikeArgs& a, hipStream_t stream);
+// device-built table of a Beta/Gamma prior: z[n], dz[2n] (slopes, then second derivatives) with
+// n = prior_table_nodes(); if max_err_bits (a zeroed device word) is given, the quintic interpolant's error
+// against the full solver is measured into it (bits of a double; compare with prior_table_direct_tol())
 int prior_table_nodes();
-hipError_t launch_prior_table(int kind, const double* args, double* z, double* dz, hipStream_t stream);
+double prior_table_direct_tol();
+hipError_t launch_prior_table(int kind, const double* args, double* z, double* dz, unsigned long long* max_err_bits,
+                              hipStream_t stream);
 
 hipError_t launch_keprv(const LoglikeArgs& a, const double* times, int Nt, unsigned include_mask, double* out,
                         hipStream_t stream);

@@ -63,6 +63,111 @@ __host__ __device__ inline Carve carve(int PB, int D, int Np, int Ni, int nlin, 
     return c;
 }
 
+// ---------------------------------------------------------------------------
+// prior transform (device functions shared by the prior kernels and the fused cube -> log-L kernel)
+// ---------------------------------------------------------------------------
+
+// Piecewise-linear inverse CDF on a host-built grid; the semantics of
+// scipy.interpolate.interp1d(cdf, x)(q) (which evaluates 1-D linear tables through
+// numpy.interp) as used by priors.py:118-124 and friends.
+__device__ double table_ppf(const rvll_prior& pr, double q)
+{
+    const int n = pr.table_n;
+    const double* xp = pr.table_cdf;
+    const double* fp = pr.table_x;
+    const bool wrapped = pr.args[2] != 0.;
+    if (wrapped) {                       // scipy rv_continuous.ppf front end
+        if (q == 0.) return pr.args[0];
+        if (q == 1.) return pr.args[1];
+        if (!(q > 0. && q < 1.)) return NAN;
+    }
+    if (!(q >= xp[0] && q <= xp[n - 1])) return NAN;   // interp1d raises ValueError here
+    // last j with xp[j] <= q
+    int lo = 0, hi = n;                  // invariant: xp[lo] <= q, (hi == n or xp[hi] > q)
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (xp[mid] <= q) lo = mid; else hi = mid;
+    }
+    const int j = lo;
+    double y;
+    if (j == n - 1) y = fp[j];
+    else if (xp[j] == q) y = fp[j];
+    else {
+        const double slope = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
+        y = slope * (q - xp[j]) + fp[j];
+        if (isnan(y)) {
+            y = slope * (q - xp[j + 1]) + fp[j + 1];
+            if (isnan(y) && fp[j] == fp[j + 1]) y = fp[j];
+        }
+    }
+    return pr.table_post ? pow(10., y) : y;
+}
+
+// Forced-identifiability transform of pypolychord's SortedUniformPrior / LogSortedUniformPrior
+// (evidence/priors.py:462-467, grouped call in evidence/polychord/__init__.py:145-160):
+//   t[N-1] = x[N-1]^(1/N),  t[n] = x[n]^(1/(n+1)) t[n+1]   over the group's members in
+// parameter order, then a + (b-a) t  (or a (b/a)^t).  Every member of kind `kind` belongs to
+// the one group, and the bounds of the LAST member are used, as the wrapper does.
+__device__ double sorted_prior(const rvll_prior* priors, int D, const double* cube_row, int d, int kind)
+{
+    int rank = 0, last = d;
+    for (int k = 0; k < D; ++k)
+        if (priors[k].kind == kind) { if (k < d) ++rank; last = k; }
+    double t = 1.;
+    int n = rank;
+    for (int k = d; k < D; ++k)
+        if (priors[k].kind == kind) { t *= pow(cube_row[k], 1.0 / (double)(n + 1)); ++n; }
+    const double lo = priors[last].args[0], hi = priors[last].args[1];
+    return kind == RVLL_PRIOR_SORTED_UNIFORM ? lo + (hi - lo) * t : lo * pow(hi / lo, t);
+}
+
+__device__ __forceinline__ bool prior_is_heavy(int kind) { return kind == RVLL_PRIOR_BETA || kind == RVLL_PRIOR_GAMMA; }
+
+// Light kinds: a handful of instructions (or one table search) for parameter d of one cube row.
+__device__ double prior_light(const rvll_prior* priors, int D, const double* cube_row, int d)
+{
+    const rvll_prior& pr = priors[d];
+    const double q = cube_row[d];
+    switch (pr.kind) {
+    case RVLL_PRIOR_UNIFORM:             // priors.py:41-42
+        return pr.args[0] + (pr.args[1] - pr.args[0]) * q;
+    case RVLL_PRIOR_JEFFREYS:            // priors.py:62-63
+        return pr.args[0] * pow(pr.args[1] / pr.args[0], q);
+    case RVLL_PRIOR_MODJEFFREYS:         // priors.py:82-83
+        return pr.args[0] * pow(1 + pr.args[1] / pr.args[0], q) - pr.args[0];
+    case RVLL_PRIOR_UNIFORMFREQUENCY:    // priors.py:100-101
+        return pr.args[0] / (1 - q * (pr.args[1] - pr.args[0]) / pr.args[1]);
+    case RVLL_PRIOR_NORMAL:              // stats.norm.ppf: loc + scale*ndtri(q)
+        return (q >= 0. && q <= 1.) ? ndtri_f64(q) * pr.args[1] + pr.args[0] : NAN;
+    case RVLL_PRIOR_LOGNORMAL:           // stats.lognorm.ppf: loc + scale*exp(s*ndtri(q))
+        return (q >= 0. && q <= 1.) ? exp(pr.args[0] * ndtri_f64(q)) * pr.args[2] + pr.args[1] : NAN;
+    case RVLL_PRIOR_TRUNCRAYLEIGH: {     // priors.py:249-252
+        const double sg = pr.args[0], xm = pr.args[1];
+        const double A = 1 - exp(-(xm * xm) / (2 * (sg * sg)));
+        return sqrt(-2 * (sg * sg) * log(1 - (q * A))); }
+    case RVLL_PRIOR_TABLE:
+        return table_ppf(pr, q);
+    case RVLL_PRIOR_ALPHA:               // stats.alpha.ppf(q, a); args[1] = Phi(a)
+        return alpha_ppf(q, pr.args[0], pr.args[1]);
+    case RVLL_PRIOR_SORTED_UNIFORM:
+    case RVLL_PRIOR_SORTED_LOGUNIFORM:
+        return sorted_prior(priors, D, cube_row, d, pr.kind);
+    default:
+        return NAN;
+    }
+}
+
+// Iterative quantiles (bracketed Newton on the regularised incomplete beta / gamma) from the device-built
+// start table (table_cdf / table_x hold z and dz/du of this prior, or null).
+__device__ double prior_heavy(const rvll_prior& pr, double q)
+{
+    const bool direct = pr.table_post != 0;   // rvll_set_priors verified the quintic interpolant of this prior
+    if (pr.kind == RVLL_PRIOR_BETA)      // stats.beta.ppf(q, a, b); args[2] = ln B(a,b)
+        return beta_ppf_table(q, pr.args[0], pr.args[1], pr.args[2], pr.table_cdf, pr.table_x, direct);
+    // stats.gamma.ppf(q, alpha, scale=1/beta); args[2] = ln Gamma(alpha)
+    return gamma_ppf_table(q, pr.args[0], pr.args[1], pr.args[2], pr.table_cdf, pr.table_x, direct);
+}
+
 // Per-block LDS views handed to eval_item (plain pointers; the kernel arguments
 // themselves are passed by reference so they stay in the scalar kernarg segment).
 struct ItemCtx {
@@ -185,9 +290,9 @@ __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx&
 }
 
 // 4 workgroups of 256 per CU (4 waves/SIMD): caps the kernel at 128 VGPRs
-template <int PREC>
-__global__ __launch_bounds__(kThreads, 4)
-void loglike_kernel(const LoglikeArgs a)
+template <int PREC, bool FUSED>
+__global__ __launch_bounds__(kThreads, 4) __attribute__((flatten))      // flatten: the prior routines of the fused
+void loglike_kernel(const LoglikeArgs a)                                // form must live under the same VGPR cap
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const Carve cv = carve(a.PB, a.D, a.Np, a.Ni, a.nlin, a.CH);
@@ -211,10 +316,32 @@ void loglike_kernel(const LoglikeArgs a)
     const int npts = (int)min((long long)a.PB, a.B - p0);
     if (npts <= 0) return;
 
-    // 1. stage this block's theta rows (one contiguous, coalesced span) + init
+    // 1. stage this block's theta rows (one contiguous, coalesced span) + init.  Fused form: the rows are
+    //    unit-cube coordinates and go through the prior transform on the way in (light kinds element by
+    //    element, then the iterative kinds compacted so that consecutive lanes all run a solve); theta is
+    //    written back for the caller.
     {
-        const double* src = a.theta + p0 * a.D;
-        for (int i = tid; i < npts * a.D; i += kThreads) theta_s[i] = src[i];
+        if (FUSED) {
+            const double* src = a.cube + p0 * a.D;
+            double* dst = a.theta_out + p0 * a.D;
+            for (int i = tid; i < npts * a.D; i += kThreads) {
+                const int pl = i / a.D, d = i - pl * a.D;
+                if (prior_is_heavy(a.priors[d].kind)) continue;
+                const double v = prior_light(a.priors, a.D, src + pl * a.D, d);
+                theta_s[i] = v;
+                dst[i] = v;
+            }
+            for (int i = tid; i < npts * a.n_heavy; i += kThreads) {
+                const int pl = i / a.n_heavy;
+                const int d = a.heavy_dims[i - pl * a.n_heavy];
+                const double v = prior_heavy(a.priors[d], src[pl * a.D + d]);
+                theta_s[pl * a.D + d] = v;
+                dst[pl * a.D + d] = v;
+            }
+        } else {
+            const double* src = a.theta + p0 * a.D;
+            for (int i = tid; i < npts * a.D; i += kThreads) theta_s[i] = src[i];
+        }
         for (int i = tid; i < npts; i += kThreads) { acc[i] = 0.; pflags[i] = 0; anyfail[i] = 0; }
         for (int i = tid; i < npts * a.Np; i += kThreads) jfail[i] = 0x7fffffff;
         if (tid == 0) nfail[0] = 0;
@@ -336,65 +463,11 @@ void loglike_kernel(const LoglikeArgs a)
 }
 
 // ---------------------------------------------------------------------------
-// prior transform
+// prior transform kernels
 // ---------------------------------------------------------------------------
 
-// Piecewise-linear inverse CDF on a host-built grid; the semantics of
-// scipy.interpolate.interp1d(cdf, x)(q) (which evaluates 1-D linear tables through
-// numpy.interp) as used by priors.py:118-124 and friends.
-__device__ double table_ppf(const rvll_prior& pr, double q)
-{
-    const int n = pr.table_n;
-    const double* xp = pr.table_cdf;
-    const double* fp = pr.table_x;
-    const bool wrapped = pr.args[2] != 0.;
-    if (wrapped) {                       // scipy rv_continuous.ppf front end
-        if (q == 0.) return pr.args[0];
-        if (q == 1.) return pr.args[1];
-        if (!(q > 0. && q < 1.)) return NAN;
-    }
-    if (!(q >= xp[0] && q <= xp[n - 1])) return NAN;   // interp1d raises ValueError here
-    // last j with xp[j] <= q
-    int lo = 0, hi = n;                  // invariant: xp[lo] <= q, (hi == n or xp[hi] > q)
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (xp[mid] <= q) lo = mid; else hi = mid;
-    }
-    const int j = lo;
-    double y;
-    if (j == n - 1) y = fp[j];
-    else if (xp[j] == q) y = fp[j];
-    else {
-        const double slope = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
-        y = slope * (q - xp[j]) + fp[j];
-        if (isnan(y)) {
-            y = slope * (q - xp[j + 1]) + fp[j + 1];
-            if (isnan(y) && fp[j] == fp[j + 1]) y = fp[j];
-        }
-    }
-    return pr.table_post ? pow(10., y) : y;
-}
-
-// Forced-identifiability transform of pypolychord's SortedUniformPrior / LogSortedUniformPrior
-// (evidence/priors.py:462-467, grouped call in evidence/polychord/__init__.py:145-160):
-//   t[N-1] = x[N-1]^(1/N),  t[n] = x[n]^(1/(n+1)) t[n+1]   over the group's members in
-// parameter order, then a + (b-a) t  (or a (b/a)^t).  Every member of kind `kind` belongs to
-// the one group, and the bounds of the LAST member are used, as the wrapper does.
-__device__ double sorted_prior(const PriorArgs& a, const double* cube_row, int d, int kind)
-{
-    int rank = 0, last = d;
-    for (int k = 0; k < a.D; ++k)
-        if (a.priors[k].kind == kind) { if (k < d) ++rank; last = k; }
-    double t = 1.;
-    int n = rank;
-    for (int k = d; k < a.D; ++k)
-        if (a.priors[k].kind == kind) { t *= pow(cube_row[k], 1.0 / (double)(n + 1)); ++n; }
-    const double lo = a.priors[last].args[0], hi = a.priors[last].args[1];
-    return kind == RVLL_PRIOR_SORTED_UNIFORM ? lo + (hi - lo) * t : lo * pow(hi / lo, t);
-}
-
-// Light kinds: a handful of instructions (or one table search) per element; one thread per
-// (live point, parameter), grid-stride.  Iterative kinds are left to prior_heavy_kernel.
+// Light kinds: one thread per (live point, parameter), grid-stride.  Iterative kinds are left to
+// prior_heavy_kernel.
 __global__ __launch_bounds__(kThreads)
 void prior_kernel(const PriorArgs a)
 {
@@ -402,45 +475,12 @@ void prior_kernel(const PriorArgs a)
     for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n;
          i += (long long)gridDim.x * kThreads) {
         const int d = (int)(i % a.D);
-        const rvll_prior& pr = a.priors[d];
-        const double q = a.cube[i];
-        double v;
-        switch (pr.kind) {
-        case RVLL_PRIOR_UNIFORM:             // priors.py:41-42
-            v = pr.args[0] + (pr.args[1] - pr.args[0]) * q; break;
-        case RVLL_PRIOR_JEFFREYS:            // priors.py:62-63
-            v = pr.args[0] * pow(pr.args[1] / pr.args[0], q); break;
-        case RVLL_PRIOR_MODJEFFREYS:         // priors.py:82-83
-            v = pr.args[0] * pow(1 + pr.args[1] / pr.args[0], q) - pr.args[0]; break;
-        case RVLL_PRIOR_UNIFORMFREQUENCY:    // priors.py:100-101
-            v = pr.args[0] / (1 - q * (pr.args[1] - pr.args[0]) / pr.args[1]); break;
-        case RVLL_PRIOR_NORMAL:              // stats.norm.ppf: loc + scale*ndtri(q)
-            v = (q >= 0. && q <= 1.) ? ndtri_f64(q) * pr.args[1] + pr.args[0] : NAN; break;
-        case RVLL_PRIOR_LOGNORMAL:           // stats.lognorm.ppf: loc + scale*exp(s*ndtri(q))
-            v = (q >= 0. && q <= 1.) ? exp(pr.args[0] * ndtri_f64(q)) * pr.args[2] + pr.args[1] : NAN; break;
-        case RVLL_PRIOR_TRUNCRAYLEIGH: {     // priors.py:249-252
-            const double sg = pr.args[0], xm = pr.args[1];
-            const double A = 1 - exp(-(xm * xm) / (2 * (sg * sg)));
-            v = sqrt(-2 * (sg * sg) * log(1 - (q * A))); break; }
-        case RVLL_PRIOR_TABLE:
-            v = table_ppf(pr, q); break;
-        case RVLL_PRIOR_ALPHA:               // stats.alpha.ppf(q, a); args[1] = Phi(a)
-            v = alpha_ppf(q, pr.args[0], pr.args[1]); break;
-        case RVLL_PRIOR_SORTED_UNIFORM:
-        case RVLL_PRIOR_SORTED_LOGUNIFORM:
-            v = sorted_prior(a, a.cube + (i - d), d, pr.kind); break;
-        case RVLL_PRIOR_BETA:
-        case RVLL_PRIOR_GAMMA:
-            continue;                        // prior_heavy_kernel
-        default:
-            v = NAN; break;
-        }
-        a.theta[i] = v;
+        if (prior_is_heavy(a.priors[d].kind)) continue;
+        a.theta[i] = prior_light(a.priors, a.D, a.cube + (i - d), d);
     }
 }
 
-// Iterative quantiles (bracketed Newton on the regularised incomplete beta / gamma): only the
-// parameters that need them, compacted so that every lane of a wave is doing a solve.
+// Only the parameters that need an iterative quantile, compacted so that every lane of a wave is doing a solve.
 __global__ __launch_bounds__(kThreads)
 void prior_heavy_kernel(const PriorArgs a)
 {
@@ -449,20 +489,13 @@ void prior_heavy_kernel(const PriorArgs a)
          i += (long long)gridDim.x * kThreads) {
         const long long b = i / a.n_heavy;
         const int d = a.heavy_dims[(int)(i - b * a.n_heavy)];
-        const rvll_prior& pr = a.priors[d];
-        const double q = a.cube[b * a.D + d];
-        double v;
-        // table_cdf / table_x hold the device-built start table (z, dz/du) of this prior, or null
-        if (pr.kind == RVLL_PRIOR_BETA)      // stats.beta.ppf(q, a, b); args[2] = ln B(a,b)
-            v = beta_ppf_table(q, pr.args[0], pr.args[1], pr.args[2], pr.table_cdf, pr.table_x);
-        else                                 // stats.gamma.ppf(q, alpha, scale=1/beta); args[2] = ln Gamma(alpha)
-            v = gamma_ppf_table(q, pr.args[0], pr.args[1], pr.args[2], pr.table_cdf, pr.table_x);
-        a.theta[b * a.D + d] = v;
+        a.theta[b * a.D + d] = prior_heavy(a.priors[d], a.cube[b * a.D + d]);
     }
 }
 
 // Tabulate one heavy prior's quantile function in smooth coordinates (rvll_special.h, "tabulated
-// starts"); runs once per rvll_set_priors, one node per thread.
+// starts"); runs once per rvll_set_priors, one node per thread.  dz holds 2 * kTableN values: slopes, then
+// the closed-form second derivatives.
 __global__ __launch_bounds__(kThreads)
 void prior_table_kernel(int kind, double a0, double a1, double a2, double* z, double* dz)
 {
@@ -474,6 +507,24 @@ void prior_table_kernel(int kind, double a0, double a1, double a2, double* z, do
     else                         gamma_table_node(a0, a2, u, zi, dzi);
     z[i] = zi;
     dz[i] = dzi;
+    dz[kTableN + i] = kind == RVLL_PRIOR_BETA ? beta_table_d2(a0, a1, u, zi, dzi) : gamma_table_d2(a0, u, zi, dzi);
+}
+
+// Measure the quintic interpolant against the full solver at every interval midpoint (where its error term
+// peaks): max |dz| over the table, as the bits of a non-negative double (integer max == float max).
+__global__ __launch_bounds__(kThreads)
+void prior_table_check_kernel(int kind, double a0, double a1, double a2, const double* z, const double* dz,
+                              unsigned long long* max_err_bits)
+{
+    const int i = blockIdx.x * kThreads + threadIdx.x;
+    if (i >= kTableN - 1) return;
+    const double u = -kTableU + (i + 0.5) * (2. * kTableU / (kTableN - 1));
+    double zt, dzt;
+    if (kind == RVLL_PRIOR_BETA) beta_table_node(a0, a1, a2, u, zt, dzt);
+    else                         gamma_table_node(a0, a2, u, zt, dzt);
+    double err = fabs(quintic_table(z, dz, u) - zt);
+    if (!(err >= 0.)) err = INFINITY;                     // NaN anywhere disqualifies the table
+    atomicMax(max_err_bits, (unsigned long long)__double_as_longlong(err));
 }
 
 __global__ __launch_bounds__(kThreads)
@@ -598,7 +649,7 @@ size_t loglike_lds_bytes(const LoglikeArgs& a)
 int loglike_blocks_per_cu(size_t lds_bytes)
 {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, loglike_kernel<RVLL_PREC_FP64>, kThreads, lds_bytes) != hipSuccess || n < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, loglike_kernel<RVLL_PREC_FP64, false>, kThreads, lds_bytes) != hipSuccess || n < 1)
         n = 1;
     return n > 8 ? 8 : n;
 }
@@ -610,9 +661,24 @@ hipError_t launch_loglike(const LoglikeArgs& a, hipStream_t stream)
     const size_t lds = loglike_lds_bytes(a);
     const dim3 grid((unsigned)blocks), block(kThreads);
     switch (a.precision) {
-    case RVLL_PREC_MIXED: hipLaunchKernelGGL(loglike_kernel<RVLL_PREC_MIXED>, grid, block, lds, stream, a); break;
-    case RVLL_PREC_FP32:  hipLaunchKernelGGL(loglike_kernel<RVLL_PREC_FP32>, grid, block, lds, stream, a); break;
-    default:              hipLaunchKernelGGL(loglike_kernel<RVLL_PREC_FP64>, grid, block, lds, stream, a); break;
+    case RVLL_PREC_MIXED: hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_MIXED, false>), grid, block, lds, stream, a); break;
+    case RVLL_PREC_FP32:  hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP32, false>), grid, block, lds, stream, a); break;
+    default:              hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP64, false>), grid, block, lds, stream, a); break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_prior_loglike(const LoglikeArgs& a, hipStream_t stream)
+{
+    if (a.B <= 0) return hipSuccess;
+    if (!a.cube || !a.theta_out || !a.priors || (a.n_heavy > 0 && !a.heavy_dims)) return hipErrorInvalidValue;
+    const long long blocks = (a.B + a.PB - 1) / a.PB;
+    const size_t lds = loglike_lds_bytes(a);
+    const dim3 grid((unsigned)blocks), block(kThreads);
+    switch (a.precision) {
+    case RVLL_PREC_MIXED: hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_MIXED, true>), grid, block, lds, stream, a); break;
+    case RVLL_PREC_FP32:  hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP32, true>), grid, block, lds, stream, a); break;
+    default:              hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP64, true>), grid, block, lds, stream, a); break;
     }
     return hipGetLastError();
 }
@@ -634,12 +700,19 @@ hipError_t launch_prior(const PriorArgs& a, hipStream_t stream)
 
 int prior_table_nodes() { return kTableN; }
 
-hipError_t launch_prior_table(int kind, const double* args, double* z, double* dz, hipStream_t stream)
+hipError_t launch_prior_table(int kind, const double* args, double* z, double* dz, unsigned long long* max_err_bits,
+                              hipStream_t stream)
 {
-    hipLaunchKernelGGL(prior_table_kernel, dim3((kTableN + kThreads - 1) / kThreads), dim3(kThreads), 0, stream,
-                       kind, args[0], args[1], args[2], z, dz);
+    const dim3 grid((kTableN + kThreads - 1) / kThreads), block(kThreads);
+    hipLaunchKernelGGL(prior_table_kernel, grid, block, 0, stream, kind, args[0], args[1], args[2], z, dz);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || !max_err_bits) return e;
+    hipLaunchKernelGGL(prior_table_check_kernel, grid, block, 0, stream, kind, args[0], args[1], args[2], z, dz,
+                       max_err_bits);
     return hipGetLastError();
 }
+
+double prior_table_direct_tol() { return kTableDirectTol; }
 
 hipError_t launch_fill_cube(double* cube, long long n, uint64_t seed, hipStream_t stream)
 {

@@ -202,6 +202,20 @@ class GpuRVModel:
     def dev_loglike(self, n):
         _abi.check(self._lib.rvll_dev_loglike(self._h, int(n)))
 
+    def prior_table_info(self):
+        """{parameter: (measured interpolation error, evaluated-by-interpolation flag)} for the Beta/Gamma priors."""
+        out = {}
+        for d, name in enumerate(self.parnames):
+            err, direct = C.c_double(), C.c_int32()
+            _abi.check(self._lib.rvll_prior_table_info(self._h, d, C.byref(err), C.byref(direct)))
+            if err.value == err.value:
+                out[name] = (err.value, bool(direct.value))
+        return out
+
+    def dev_prior_loglike(self, n):
+        """cube -> theta -> log-L in one launch (the prior transform runs in the log-L kernel's staging step)."""
+        _abi.check(self._lib.rvll_dev_prior_loglike(self._h, int(n)))
+
     def dev_flip_lane(self):
         """Alternate the pipeline lane between independent device-resident batches (include/rvll.h)."""
         return self._lib.rvll_dev_flip_lane(self._h)

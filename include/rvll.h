@@ -196,6 +196,13 @@ int rvll_destroy(rvll_handle* h);
 
 /* ---- priors -------------------------------------------------------------- */
 int rvll_set_priors(rvll_handle* h, const rvll_prior* priors, int32_t ndim);
+/* Beta and Gamma quantiles (scipy.stats.beta/gamma.ppf, evidence/priors.py:397-398, 424-425) have no closed
+ * form: rvll_set_priors lets the device tabulate each one once and MEASURES the table's quintic interpolant
+ * against the full iterative solver.  max_err = that measured error (relative, in the interpolation
+ * coordinate; NaN for parameters without such a table); direct = 1 if it is small enough that elements are
+ * evaluated by interpolation alone, 0 if every element still runs a Newton step on the incomplete
+ * beta/gamma function.  Diagnostics only.                                                               */
+int rvll_prior_table_info(rvll_handle* h, int32_t dim, double* max_err, int32_t* direct);
 
 /* ---- the hot calls (host buffers in, host buffers out) ------------------- */
 /* theta: [B, D] row-major.  logL: [B].  flags: [B] or NULL.                  */
@@ -217,6 +224,11 @@ int rvll_dev_fill_cube(rvll_handle* h, int64_t B, uint64_t seed);
 /* Launch on the handle's compute stream; asynchronous.                        */
 int rvll_dev_prior(rvll_handle* h, int64_t B);                 /* cube -> theta  */
 int rvll_dev_loglike(rvll_handle* h, int64_t B);               /* theta -> logL  */
+/* One launch: the log-L kernel's staging step applies the prior transform to the resident cube rows, keeps
+ * theta in LDS for the evaluation and writes it to the resident theta buffer too (prior(cube) followed by
+ * loglike(theta) of evidence/polychord/__init__.py:130-171 for a whole batch).  Results are bit-identical to
+ * rvll_dev_prior followed by rvll_dev_loglike.                                                           */
+int rvll_dev_prior_loglike(rvll_handle* h, int64_t B);         /* cube -> theta, logL */
 int rvll_dev_download(rvll_handle* h, int64_t B, double* theta /*or NULL*/,
                       double* logL /*or NULL*/, int32_t* flags /*or NULL*/);
 int rvll_dev_sync(rvll_handle* h);

@@ -10,14 +10,45 @@ HM void hm_beta_ppf(const double* q, long n, double a, double b, double lbeta, d
 HM void hm_gamma_ppf(const double* q, long n, double alpha, double beta, double lgam, double* out) { for (long i = 0; i < n; ++i) out[i] = rvll::gamma_ppf(q[i], alpha, beta, lgam); }
 HM void hm_alpha_ppf(const double* q, long n, double a, double phi_a, double* out) { for (long i = 0; i < n; ++i) out[i] = rvll::alpha_ppf(q[i], a, phi_a); }
 HM void hm_betainc(const double* x, long n, double a, double b, double lbeta, double* out) { for (long i = 0; i < n; ++i) out[i] = rvll::betainc_lower(a, b, x[i], lbeta); }
-HM void hm_beta_table(double a, double b, double lbeta, double* z, double* dz) {
-    const double h = 2. * rvll::kTableU / (rvll::kTableN - 1);
-    for (int i = 0; i < rvll::kTableN; ++i) rvll::beta_table_node(a, b, lbeta, -rvll::kTableU + i * h, z[i], dz[i]); }
-HM void hm_beta_ppf_table(const double* q, long n, double a, double b, double lbeta, const double* z, const double* dz, double* out) {
-    for (long i = 0; i < n; ++i) out[i] = rvll::beta_ppf_table(q[i], a, b, lbeta, z, dz); }
-HM void hm_gamma_table(double alpha, double lgam, double* z, double* dz) {
-    const double h = 2. * rvll::kTableU / (rvll::kTableN - 1);
-    for (int i = 0; i < rvll::kTableN; ++i) rvll::gamma_table_node(alpha, lgam, -rvll::kTableU + i * h, z[i], dz[i]); }
-HM void hm_gamma_ppf_table(const double* q, long n, double alpha, double beta, double lgam, const double* z, const double* dz, double* out) {
-    for (long i = 0; i < n; ++i) out[i] = rvll::gamma_ppf_table(q[i], alpha, beta, lgam, z, dz); }
+// tables as prior_table_kernel builds them: z[n]; dz[2n] = slopes, then second derivatives.  The return value
+// is what prior_table_check_kernel measures: max |quintic interpolant - full solver| over the interval midpoints.
+HM double hm_beta_table(double a, double b, double lbeta, double* z, double* dz) {
+    const int n = rvll::kTableN;
+    const double h = 2. * rvll::kTableU / (n - 1);
+    for (int i = 0; i < n; ++i) {
+        const double u = -rvll::kTableU + i * h;
+        rvll::beta_table_node(a, b, lbeta, u, z[i], dz[i]);
+        dz[n + i] = rvll::beta_table_d2(a, b, u, z[i], dz[i]);
+    }
+    double worst = 0.;
+    for (int i = 0; i < n - 1; ++i) {
+        const double u = -rvll::kTableU + (i + 0.5) * h;
+        double zt, dzt;
+        rvll::beta_table_node(a, b, lbeta, u, zt, dzt);
+        const double err = fabs(rvll::quintic_table(z, dz, u) - zt);
+        if (!(err <= worst)) worst = err;
+    }
+    return worst; }
+HM void hm_beta_ppf_table(const double* q, long n, double a, double b, double lbeta, const double* z, const double* dz, int direct, double* out) {
+    for (long i = 0; i < n; ++i) out[i] = rvll::beta_ppf_table(q[i], a, b, lbeta, z, dz, direct != 0); }
+HM double hm_gamma_table(double alpha, double lgam, double* z, double* dz) {
+    const int n = rvll::kTableN;
+    const double h = 2. * rvll::kTableU / (n - 1);
+    for (int i = 0; i < n; ++i) {
+        const double u = -rvll::kTableU + i * h;
+        rvll::gamma_table_node(alpha, lgam, u, z[i], dz[i]);
+        dz[n + i] = rvll::gamma_table_d2(alpha, u, z[i], dz[i]);
+    }
+    double worst = 0.;
+    for (int i = 0; i < n - 1; ++i) {
+        const double u = -rvll::kTableU + (i + 0.5) * h;
+        double zt, dzt;
+        rvll::gamma_table_node(alpha, lgam, u, zt, dzt);
+        const double err = fabs(rvll::quintic_table(z, dz, u) - zt);
+        if (!(err <= worst)) worst = err;
+    }
+    return worst; }
+HM void hm_gamma_ppf_table(const double* q, long n, double alpha, double beta, double lgam, const double* z, const double* dz, int direct, double* out) {
+    for (long i = 0; i < n; ++i) out[i] = rvll::gamma_ppf_table(q[i], alpha, beta, lgam, z, dz, direct != 0); }
+HM double hm_table_direct_tol(void) { return rvll::kTableDirectTol; }
 HM int hm_table_n(void) { return rvll::kTableN; }

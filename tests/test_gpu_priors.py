@@ -62,6 +62,42 @@ def test_fused_prior_loglike_equals_two_calls(gpu_required):
     assert np.all((theta[:, w.parnames.index("planet1_ecc")] >= 0) & (theta[:, w.parnames.index("planet1_ecc")] <= 1))
 
 
+@pytest.mark.parametrize("n", [1, 100, 777, 20000])
+def test_one_launch_form_is_bit_identical_for_every_prior_family(gpu_required, n):
+    """cube -> theta -> log-L in ONE launch (the prior transform runs in the log-L kernel's staging step)
+    against prior kernel + log-L kernel, with every family of evidence/priors.py on some parameter: light,
+    table, iterative (Beta, Gamma) and the sorted groups; small (zero-copy), ragged and large batches;
+    host-buffer and device-resident entry points."""
+    from evidence_amd import priors as P
+    w = make_workload(3)
+    fams = {
+        "harps_jitter": P.TruncatedRayleigh(3.0, 30.0), "harps_offset": P.Normal(0.5, 4.0),
+        "hires_jitter": P.Gamma(2.0, 0.7), "hires_offset": P.Binormal(-3.0, 1.0, 4.0, 2.0, 0.3),
+        "planet1_ecc": P.Beta(0.867, 3.03), "planet1_k1": P.ModJeffreys(1.0, 80.0), "planet1_ma0": P.Sine(0.0, 180.0),
+        "planet1_omega": P.Uniform(0.0, 6.283185307179586), "planet1_period": P.SortedLogUniform(1.5, 900.0),
+        "planet2_ecc": P.TruncatedUNormal(0.1, 0.2, 0.0, 0.95), "planet2_k1": P.LogNormal(0.8, 0.0, 5.0),
+        "planet2_ma0": P.AsymmetricNormal(3.0, 0.5, 1.5), "planet2_omega": P.PowerLaw(-0.5, 0.1, 6.0),
+        "planet2_period": P.SortedLogUniform(1.5, 900.0),
+        "planet3_ecc": P.Beta(2.0, 5.0), "planet3_k1": P.Alpha(3.0), "planet3_ma0": P.DoublePowerLaw(0.5, -1.5, 2.0, 0.5, 6.0),
+        "planet3_omega": P.UniformFrequency(0.5, 6.0), "planet3_period": P.SortedLogUniform(1.5, 900.0),
+    }
+    assert sorted(fams) == list(w.parnames), sorted(set(w.parnames) ^ set(fams))
+    cube = np.random.default_rng(n).random((n, w.ndim))
+    with GpuRVModel(w.fixedpardict, w.table, w.parnames, priordict=fams) as m:
+        theta2 = m.prior_transform_batch(cube)
+        logl2 = m.log_likelihood_batch(theta2)
+        theta, logl = m.prior_loglike_batch(cube)                        # host buffers, one launch
+        m.dev_upload_cube(cube)
+        m.dev_prior_loglike(n)                                           # device resident, one launch
+        th3, ll3, _ = m.dev_download(n, theta=True)
+    same = lambda a, b: np.array_equal(a, b, equal_nan=True)
+    assert same(theta, theta2) and same(logl, logl2)
+    assert same(th3, theta2) and same(ll3, logl2)
+    assert np.isfinite(theta).mean() > 0.99
+    p = theta[:, [w.parnames.index(f"planet{k}_period") for k in (1, 2, 3)]]
+    assert (np.diff(p, axis=1) >= 0).all()                                # the sorted group came out ordered
+
+
 def test_prior_before_set_priors_is_an_error(gpu_required):
     from evidence_amd import RvllError
     w = make_workload(1)

@@ -83,29 +83,56 @@ def test_sincos_host_build_accuracy(hm):
     assert np.max(np.abs(c.astype(np.longdouble) - np.cos(xl))) <= 1.5 * 2.0 ** -53
 
 
-def test_tabulated_start_quantiles_equal_the_full_solver(hm):
-    """The device builds a start table per Beta/Gamma prior and polishes once; same answers as the full solver."""
+def test_tabulated_quantiles_equal_the_full_solver(hm):
+    """The device tabulates each Beta/Gamma prior once.  Cubic start + one Newton polish lands on the full
+    solver's answer; the quintic interpolant, whose error against the full solver is MEASURED when the table is
+    built, replaces the polish when that error is below the tolerance — both forms are checked here."""
     from scipy import special as sp
     n = hm.hm_table_n()
+    hm.hm_beta_table.restype = C.c_double
+    hm.hm_gamma_table.restype = C.c_double
+    hm.hm_table_direct_tol.restype = C.c_double
+    tol = hm.hm_table_direct_tol()
     rng = np.random.default_rng(2)
     q = np.concatenate([rng.random(20000), 10.0 ** rng.uniform(-12, -1, 2000), 1 - 10.0 ** rng.uniform(-12, -1, 2000),
                         [0.0, 1.0, 1e-14, 1 - 1e-15, 0.5]])
     mid = (q >= 1e-12) & (q <= 1 - 1e-12)
-    for a, b in [(0.867, 3.03), (2, 5), (12, 1.5), (50, 80), (0.1, 0.2)]:
+    report = []
+    for a, b in [(0.867, 3.03), (2, 5), (12, 1.5), (50, 80), (0.1, 0.2), (0.5, 0.5), (1.0, 1.0), (300.0, 2.0)]:
         lb = float(sp.betaln(a, b))
-        z, dz, out = np.empty(n), np.empty(n), np.empty_like(q)
-        hm.hm_beta_table(C.c_double(a), C.c_double(b), C.c_double(lb), z.ctypes.data_as(dp), dz.ctypes.data_as(dp))
+        z, dz, out = np.empty(n), np.empty(2 * n), np.empty_like(q)
+        err = hm.hm_beta_table(C.c_double(a), C.c_double(b), C.c_double(lb), z.ctypes.data_as(dp), dz.ctypes.data_as(dp))
         assert np.isfinite(z).all() and np.isfinite(dz).all() and np.all(np.diff(z) > 0)
-        hm.hm_beta_ppf_table(q.ctypes.data_as(dp), C.c_long(q.size), C.c_double(a), C.c_double(b), C.c_double(lb),
-                             z.ctypes.data_as(dp), dz.ctypes.data_as(dp), out.ctypes.data_as(dp))
         full = call(hm, "hm_beta_ppf", q, a, b, lb)
-        assert pc.rel_err(out[mid], full[mid]).max() <= 1e-13, (a, b)
-        assert out[-5] == 0.0 and out[-4] == 1.0
-    for al, be in [(2, 3), (0.7, 0.1), (25, 2)]:
+        for direct in (0, 1):
+            hm.hm_beta_ppf_table(q.ctypes.data_as(dp), C.c_long(q.size), C.c_double(a), C.c_double(b), C.c_double(lb),
+                                 z.ctypes.data_as(dp), dz.ctypes.data_as(dp), C.c_int(direct), out.ctypes.data_as(dp))
+            assert out[-5] == 0.0 and out[-4] == 1.0
+            worst = pc.rel_err(out[mid], full[mid]).max()
+            if direct == 0:
+                assert worst <= 1e-13, (a, b)
+            else:
+                report.append(("beta", a, b, err, worst))
+                # the measured table error bounds what interpolation alone delivers (z = logit x: d ln x = (1-x) dz)
+                assert worst <= max(4 * err, 2e-15) + 1e-15, (a, b, err, worst)
+                if err <= tol:
+                    assert worst <= 1e-13, (a, b, err, worst)
+    for al, be in [(2, 3), (0.7, 0.1), (25, 2), (0.05, 1.0), (1.0, 1.0)]:
         lg = math.lgamma(al)
-        z, dz, out = np.empty(n), np.empty(n), np.empty_like(q)
-        hm.hm_gamma_table(C.c_double(al), C.c_double(lg), z.ctypes.data_as(dp), dz.ctypes.data_as(dp))
-        hm.hm_gamma_ppf_table(q.ctypes.data_as(dp), C.c_long(q.size), C.c_double(al), C.c_double(be), C.c_double(lg),
-                              z.ctypes.data_as(dp), dz.ctypes.data_as(dp), out.ctypes.data_as(dp))
+        z, dz, out = np.empty(n), np.empty(2 * n), np.empty_like(q)
+        err = hm.hm_gamma_table(C.c_double(al), C.c_double(lg), z.ctypes.data_as(dp), dz.ctypes.data_as(dp))
         full = call(hm, "hm_gamma_ppf", q, al, be, lg)
-        assert pc.rel_err(out[mid], full[mid]).max() <= 1e-13, (al, be)
+        for direct in (0, 1):
+            hm.hm_gamma_ppf_table(q.ctypes.data_as(dp), C.c_long(q.size), C.c_double(al), C.c_double(be), C.c_double(lg),
+                                  z.ctypes.data_as(dp), dz.ctypes.data_as(dp), C.c_int(direct), out.ctypes.data_as(dp))
+            worst = pc.rel_err(out[mid], full[mid]).max()
+            if direct == 0:
+                assert worst <= 1e-13, (al, be)
+            else:
+                report.append(("gamma", al, be, err, worst))
+                assert worst <= max(4 * err, 2e-15) + 1e-15, (al, be, err, worst)
+                if err <= tol:
+                    assert worst <= 1e-13, (al, be, err, worst)
+    print(report)
+    # the shapes the shipped configs use must qualify for the interpolation-only path
+    assert [r[3] <= tol for r in report if r[:3] in (("beta", 0.867, 3.03), ("beta", 2, 5))] == [True, True]
