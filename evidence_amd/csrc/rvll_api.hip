@@ -14,6 +14,7 @@
 #include <new>
 #include <string>
 #include <vector>
+#include <unordered_map>
 
 // the C-ABI entry points are the only exported symbols (built with -fvisibility=hidden)
 #pragma GCC visibility push(default)
@@ -115,6 +116,8 @@ void dev_free(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
 }  // namespace
 
 constexpr int kMaxLanes = 4;
+// rvll_loglike_batch: host batches from kSplitMinPoints on go up in overlapped chunks of about kSplitChunkPoints
+constexpr long long kSplitMinPoints = 16384, kSplitChunkPoints = 32768, kSplitMaxChunks = 8;
 constexpr long long kFusedMaxPoints = 4096;   // rvll_prior_loglike_batch: one launch up to here, two beyond
 
 struct rvll_handle {
@@ -170,8 +173,8 @@ struct rvll_handle {
 
     // geometry
     int pb_override = 0;
-    long long geo_B = -1;     // batch size the cached geometry was chosen for
-    int geo_pb = 1;
+    std::unordered_map<long long, int> geo;     // batch size -> points per workgroup chosen for it
+    std::unordered_map<size_t, int> occ_by_lds; // dynamic LDS bytes -> resident workgroups per CU
     int chunk_items = 4096;
     int n_cu = 256;
 
@@ -259,7 +262,7 @@ size_t lds_bytes_for(const rvll_handle* h, int pb)
 int choose_points_per_block(rvll_handle* h, long long B)
 {
     if (h->pb_override > 0) return std::min(h->pb_override, rvll::kMaxPointsPerBlock);
-    if (h->geo_B == B) return h->geo_pb;
+    { auto it = h->geo.find(B); if (it != h->geo.end()) return it->second; }
     // Cost model fitted to the MI355X sweeps in profiles/r01_sweep_configs.txt.  A workgroup costs its CU
     // W = ceil(PB*Ne/64)/4 wave-rounds per SIMD (a partly filled last round only occupies the waves that
     // have items), plus ~0.6 for staging, decode, barriers and the reduction, plus ~0.5 per extra LDS
@@ -280,7 +283,10 @@ int choose_points_per_block(rvll_handle* h, long long B)
                                                    : (double)pb * std::ceil((double)Ne / h->chunk_items);
         const double W = (double)((items + rvll::kWave - 1) / rvll::kWave) / 4.0 + 0.6 + 0.5 * (chunks - 1.0);
         const double blocks = std::ceil((double)B / pb);
-        const int occ = rvll::loglike_blocks_per_cu(lds);
+        int occ;
+        { auto it = h->occ_by_lds.find(lds);
+          if (it != h->occ_by_lds.end()) occ = it->second;
+          else { occ = rvll::loglike_blocks_per_cu(lds); h->occ_by_lds[lds] = occ; } }
         // with two launches in flight (pipeline lanes) the next launch fills the tail, so the tail term drops out
         double remaining = std::ceil(blocks / h->n_cu), cost = h->pipelined ? 0.0 : 0.5 * W;
         while (remaining > 0) {
@@ -291,8 +297,8 @@ int choose_points_per_block(rvll_handle* h, long long B)
         }
         if (cost < best_cost * (1.0 - 1e-9)) { best_cost = cost; best = pb; }
     }
-    h->geo_B = B;
-    h->geo_pb = best;
+    if (h->geo.size() > 64) h->geo.clear();
+    h->geo[B] = best;
     return best;
 }
 
@@ -764,7 +770,7 @@ int rvll_dev_flip_lane(rvll_handle* h)
 {
     if (!h) return fail(RVLL_E_INVALID, "null handle");
     h->logl_cur = (h->logl_cur + 1) % (h->nccl_comm[0] ? h->nlanes : h->nlanes_dev);
-    if (!h->pipelined) { h->pipelined = true; h->geo_B = -1; }
+    if (!h->pipelined) { h->pipelined = true; h->geo.clear(); }
     return h->logl_cur;
 }
 
@@ -823,6 +829,7 @@ int rvll_dev_time_loglike(rvll_handle* h, int64_t B, int32_t warmup, int32_t ite
 // ---- host-buffer hot calls -------------------------------------------------------
 int rvll_loglike_batch(rvll_handle* h, const double* theta, int64_t B, double* logL, int32_t* flags)
 {
+    if (!h) return fail(RVLL_E_INVALID, "null handle");
     if (B < 0) return fail(RVLL_E_INVALID, "B < 0");
     if (B == 0) return use_device(h);
     if (!theta || !logL) return fail(RVLL_E_INVALID, "theta/logL is null");
@@ -846,6 +853,33 @@ int rvll_loglike_batch(rvll_handle* h, const double* theta, int64_t B, double* l
         if (flags) memcpy(flags, static_cast<char*>(h->pin_out) + sizeof(double) * (size_t)B, sizeof(int32_t) * (size_t)B);
         return RVLL_OK;
     }
+    int nsplit = B >= kSplitMinPoints ? (int)std::min<long long>(kSplitMaxChunks, std::max<long long>(2, B / kSplitChunkPoints)) : 1;
+    if (const char* e = getenv("RVLL_SPLIT")) nsplit = std::max(1, std::min(64, atoi(e)));   // measurement switch
+    if (nsplit > 1 && B >= 2 * nsplit) {
+        // Large host batch: chunks alternate between two streams.  A copy from pageable memory occupies the
+        // calling thread while the runtime stages it, so the upload of chunk i+1 overlaps the kernel of chunk i;
+        // all chunks write into the same log-L / flags buffers and come back with one download.
+        int rc = rvll_dev_reserve(h, B);
+        if (rc) return rc;
+        rc = sync_other_lanes(h);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(h->compute));
+        const long long D = h->L.ndim;
+        for (int c = 0; c < nsplit; ++c) {
+            const long long lo = B * c / nsplit, hi = B * (c + 1) / nsplit;
+            hipStream_t st = h->lanes[c & 1];
+            HIP_TRY(hipMemcpyAsync(h->d_theta + lo * D, theta + lo * D, sizeof(double) * (size_t)((hi - lo) * D),
+                                   hipMemcpyHostToDevice, st));
+            rvll::LoglikeArgs a;
+            rc = build_args(h, h->d_theta + lo * D, h->d_logL2[0] + lo, h->d_flags2[0] + lo, hi - lo, &a);
+            if (rc) return rc;
+            HIP_TRY(rvll::launch_loglike(a, st));
+        }
+        HIP_TRY(hipStreamSynchronize(h->lanes[1]));
+        h->theta_async = false;
+        h->logl_last = 0;
+        return rvll_dev_download(h, B, nullptr, logL, flags);
+    }
     int rc = rvll_dev_upload_theta(h, theta, B);
     if (rc) return rc;
     rc = rvll_dev_loglike(h, B);
@@ -855,6 +889,7 @@ int rvll_loglike_batch(rvll_handle* h, const double* theta, int64_t B, double* l
 
 int rvll_prior_batch(rvll_handle* h, const double* cube, int64_t B, double* theta)
 {
+    if (!h) return fail(RVLL_E_INVALID, "null handle");
     if (B < 0) return fail(RVLL_E_INVALID, "B < 0");
     if (h && !h->have_priors) return fail(RVLL_E_NOPRIORS, "rvll_set_priors has not been called");
     if (B == 0) return use_device(h);
@@ -869,6 +904,7 @@ int rvll_prior_batch(rvll_handle* h, const double* cube, int64_t B, double* thet
 int rvll_prior_loglike_batch(rvll_handle* h, const double* cube, int64_t B,
                              double* theta_out, double* logL, int32_t* flags)
 {
+    if (!h) return fail(RVLL_E_INVALID, "null handle");
     if (B < 0) return fail(RVLL_E_INVALID, "B < 0");
     if (h && !h->have_priors) return fail(RVLL_E_NOPRIORS, "rvll_set_priors has not been called");
     if (B == 0) return use_device(h);
@@ -1041,7 +1077,7 @@ int rvll_allgather_logl(rvll_handle* h, int64_t B_local)
     h->gather_last = lane;
     if (h->nlanes > 1) {
         h->logl_cur = (lane + 1) % h->nlanes; // the next step runs on the next lane
-        if (!h->pipelined) { h->pipelined = true; h->geo_B = -1; }
+        if (!h->pipelined) { h->pipelined = true; h->geo.clear(); }
     }
     return RVLL_OK;
 }

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Host-buffer log-L call (theta upload + kernel + log-L download) for large batches: whole batch in one go
+(RVLL_SPLIT=1) vs 2..16 overlapped chunks vs the built-in choice.  Run on the GPU box."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from evidence_amd import GpuRVModel
+from evidence_amd.synthetic import make_workload
+
+w = make_workload(3)
+with GpuRVModel(w.fixedpardict, w.table, w.parnames) as m:
+    for n in (8192, 16384, 32768, 65536, 131072, 262144):
+        theta = w.sample_theta(n, 1)
+        ref = None
+        for mode in ("1", "2", "4", "8", "16", "default"):
+            if mode == "default":
+                os.environ.pop("RVLL_SPLIT", None)
+            else:
+                os.environ["RVLL_SPLIT"] = mode
+            for _ in range(5):
+                out = m.log_likelihood_batch(theta)
+            reps = 50
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                out = m.log_likelihood_batch(theta)
+            dt = (time.perf_counter() - t0) / reps
+            if ref is None:
+                ref = out
+            print(f"n={n:7d} {mode:5s} {dt*1e6:8.1f} us  {n/dt:.3e} evals/s  identical={np.array_equal(out, ref)}", flush=True)

@@ -202,3 +202,19 @@ def test_single_lane_fallback_gathers_in_stream(gpu_required, monkeypatch):
             m.allgather_logl(len(case.theta))
         assert np.array_equal(m.download_gathered(len(case.theta)), want)
         m.comm_destroy()
+
+
+@pytest.mark.parametrize("n", [16384, 40001, 131072])
+def test_large_host_batches_go_up_in_overlapped_chunks(gpu_required, n, monkeypatch):
+    """From 16384 points on, rvll_loglike_batch uploads and evaluates a host batch in chunks on two streams
+    (upload of chunk i+1 overlaps the kernel of chunk i): same bits as the single-shot path, ragged sizes too."""
+    from evidence_amd.synthetic import make_workload
+    w = make_workload(3)
+    theta = w.sample_theta(n, seed=n)
+    with GpuRVModel(w.fixedpardict, w.table, w.parnames) as m:
+        got, flags = m.log_likelihood_batch(theta, return_flags=True)
+        monkeypatch.setenv("RVLL_SPLIT", "1")
+        whole, flags1 = m.log_likelihood_batch(theta, return_flags=True)
+        monkeypatch.setenv("RVLL_SPLIT", "7")
+        seven = m.log_likelihood_batch(theta)
+    assert np.array_equal(got, whole) and np.array_equal(flags, flags1) and np.array_equal(seven, whole)
