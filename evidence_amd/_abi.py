@@ -114,6 +114,8 @@ PROTOTYPES = {
     "rvll_comm_init": (C.c_int, [Handle, C.POINTER(C.c_ubyte), C.c_int32, C.c_int32]),
     "rvll_allgather_logl": (C.c_int, [Handle, C.c_int64]),
     "rvll_download_gathered": (C.c_int, [Handle, C.c_int64, _dp]),
+    "rvll_allgather_theta": (C.c_int, [Handle, C.c_int64]),
+    "rvll_download_gathered_theta": (C.c_int, [Handle, C.c_int64, _dp]),
     "rvll_comm_destroy": (C.c_int, [Handle]),
     "rvll_kep_rv_batch": (C.c_int, [Handle, _dp, C.c_int64, _dp, C.c_int32, C.c_uint32, _dp]),
     "rvll_fip_accumulate": (C.c_int, [C.c_int32, _dp, _dp, C.c_int32, _dp, _dp, C.POINTER(C.c_int64), C.c_int32,

@@ -184,6 +184,8 @@ struct rvll_handle {
     int nlanes = 1;
     long long gather_cap = 0;
     double* d_gather2[kMaxLanes] = {};
+    double* d_gather_theta = nullptr;           // [nranks * B_local, D] (rvll_allgather_theta)
+    long long gather_theta_cap = 0;             // in rows
     int gather_last = 0;
 };
 
@@ -506,6 +508,7 @@ int rvll_destroy(rvll_handle* h)
     free_priors(h);
     dev_free(h->d_theta); dev_free(h->d_cube);
     for (int l = 0; l < kMaxLanes; ++l) { dev_free(h->d_logL2[l]); dev_free(h->d_flags2[l]); dev_free(h->d_gather2[l]); }
+    dev_free(h->d_gather_theta);
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     dev_free(h->d_t); dev_free(h->d_y); dev_free(h->d_s2); dev_free(h->d_inst); dev_free(h->d_linpar);
@@ -1079,6 +1082,40 @@ int rvll_allgather_logl(rvll_handle* h, int64_t B_local)
         h->logl_cur = (lane + 1) % h->nlanes; // the next step runs on the next lane
         if (!h->pipelined) { h->pipelined = true; h->geo.clear(); }
     }
+    return RVLL_OK;
+}
+
+int rvll_allgather_theta(rvll_handle* h, int64_t B_local)
+{
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!h->nccl_comm[0]) return fail(RVLL_E_RCCL, "rvll_comm_init has not been called");
+    if (B_local < 1 || B_local > h->cap) return fail(RVLL_E_INVALID, "B_local %lld outside reserved capacity %lld", (long long)B_local, h->cap);
+    const long long total = (long long)B_local * h->nranks;
+    const size_t D = (size_t)std::max(1, h->L.ndim);
+    if (total > h->gather_theta_cap) {
+        HIP_TRY(hipStreamSynchronize(h->compute));
+        dev_free(h->d_gather_theta);
+        h->gather_theta_cap = 0;
+        HIP_TRY(hipMalloc(&h->d_gather_theta, sizeof(double) * D * (size_t)total));
+        h->gather_theta_cap = total;
+    }
+    // theta is written on lane 0's stream (upload or prior kernel); the gather queues behind it there, on
+    // lane 0's communicator — the same stream and communicator lane 0's log-L gathers use, so the two never
+    // run concurrently on one communicator
+    RCCL_TRY(g_rccl.AllGather(h->d_theta, h->d_gather_theta, (size_t)B_local * D, kNcclFloat64,
+                              h->nccl_comm[0], h->compute));
+    return RVLL_OK;
+}
+
+int rvll_download_gathered_theta(rvll_handle* h, int64_t B_total, double* theta_all)
+{
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!theta_all || B_total < 1 || B_total > h->gather_theta_cap) return fail(RVLL_E_INVALID, "bad gathered theta download");
+    HIP_TRY(hipMemcpyAsync(theta_all, h->d_gather_theta, sizeof(double) * (size_t)B_total * (size_t)h->L.ndim,
+                           hipMemcpyDeviceToHost, h->compute));
+    HIP_TRY(hipStreamSynchronize(h->compute));
     return RVLL_OK;
 }
 

@@ -271,5 +271,14 @@ class GpuRVModel:
         _abi.check(self._lib.rvll_download_gathered(self._h, int(n_total), _abi.as_dp(out)))
         return out
 
+    def allgather_theta(self, n_local):
+        """All-gather the resident theta rows (produced on the device by the prior transform) of every rank."""
+        _abi.check(self._lib.rvll_allgather_theta(self._h, int(n_local)))
+
+    def download_gathered_theta(self, n_total):
+        out = np.empty((int(n_total), self.ndim), dtype=np.float64)
+        _abi.check(self._lib.rvll_download_gathered_theta(self._h, int(n_total), _abi.as_dp(out)))
+        return out
+
     def comm_destroy(self):
         _abi.check(self._lib.rvll_comm_destroy(self._h))

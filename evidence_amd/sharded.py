@@ -2,7 +2,8 @@
 per-shard log-L returns every value to every rank — in particular to rank 0, which owns the
 sampler's replacement step.  This replaces the MPI fan-out the reference leaves to its third-party
 samplers (evidence/polychord/__init__.py:21-29,176-199; evidence/ultranest/__init__.py:21-29,151-194);
-there is no other exchange on this path, so there is no other collective.
+there is no other exchange on this path, so there is no other collective — except that when theta itself was
+produced on the device from a cube shard (ShardedPriorLogLike), its rows travel back the same way.
 
 Two transports for the same partition:
   "rccl"  the device buffer the log-L kernel wrote is all-gathered in place by RCCL over xGMI on the
@@ -83,6 +84,54 @@ class ShardedLogLike:
         parts = [torch.empty(pad, dtype=torch.float64) for _ in range(self.world)]
         dist.all_gather(parts, mine)
         return unpad(torch.cat(parts).numpy(), n, self.world)
+
+
+class ShardedPriorLogLike:
+    """prior(cube) + loglike(theta) over a batch of unit-cube rows every rank holds: each rank transforms and
+    evaluates its rows on its GPU, then TWO all-gathers — log-L, and the theta rows the prior kernel produced
+    on the device (the sampler on rank 0 needs the physical parameters of the points it keeps).
+    Returns (theta [n, ndim], logL [n]) on every rank.  Transports as in ShardedLogLike; with "dist" the
+    evaluation is `evaluate(cubes) -> (theta, logL)` (GpuRVModel.prior_loglike_batch in the product)."""
+
+    def __init__(self, rank: int, world: int, evaluate: Callable = None, model=None, transport: str = "dist"):
+        if transport not in ("dist", "rccl"):
+            raise ValueError(transport)
+        if transport == "rccl" and model is None:
+            raise ValueError("the rccl transport gathers the model's device buffers: pass model=")
+        if evaluate is None and model is None:
+            raise ValueError("pass evaluate= or model=")
+        self.rank, self.world, self.model, self.transport = rank, world, model, transport
+        self.evaluate = evaluate if evaluate is not None else model.prior_loglike_batch
+
+    def __call__(self, cubes: np.ndarray):
+        cubes = np.ascontiguousarray(cubes, dtype=np.float64)
+        n, ndim = cubes.shape
+        if n == 0:
+            return np.empty((0, ndim)), np.empty(0)
+        lo, hi = partition(n, self.world)[self.rank]
+        pad = padded_count(n, self.world)
+        rows = np.full((pad, ndim), 0.5)                     # padding rows: the middle of the cube is always valid
+        rows[: hi - lo] = cubes[lo:hi]
+        if self.transport == "rccl":
+            m = self.model
+            m.dev_upload_cube(rows)
+            m.dev_prior_loglike(pad)
+            m.allgather_theta(pad)
+            m.allgather_logl(pad)
+            theta_all = m.download_gathered_theta(self.world * pad)
+            logl_all = m.download_gathered(self.world * pad)
+        else:
+            import torch
+            import torch.distributed as dist
+            th, ll = self.evaluate(rows)
+            mine = torch.from_numpy(np.concatenate([np.asarray(th, dtype=np.float64).reshape(pad, ndim),
+                                                    np.asarray(ll, dtype=np.float64).reshape(pad, 1)], axis=1).copy())
+            parts = [torch.empty_like(mine) for _ in range(self.world)]
+            dist.all_gather(parts, mine)
+            both = torch.cat(parts).numpy()
+            theta_all, logl_all = both[:, :ndim], both[:, ndim]
+        keep = np.concatenate([np.arange(r * pad, r * pad + (h - l)) for r, (l, h) in enumerate(partition(n, self.world))])
+        return np.ascontiguousarray(theta_all[keep]), np.ascontiguousarray(logl_all[keep])
 
 
 class MultiDeviceLogLike:

@@ -258,6 +258,11 @@ int rvll_comm_init(rvll_handle* h, const unsigned char id[RVLL_COMM_ID_BYTES],
  * overlaps the kernel of the next without cross-stream events; rvll_download_gathered returns the last one. */
 int rvll_allgather_logl(rvll_handle* h, int64_t B_local);
 int rvll_download_gathered(rvll_handle* h, int64_t B_total, double* logL_all);
+/* When theta was produced on the device (rvll_dev_prior / rvll_dev_prior_loglike on a cube shard), the sampler
+ * on rank 0 also needs the physical parameters of the points it keeps: one more all-gather, of the B_local x
+ * ndim theta rows, rank-major like the log-L gather.  Asynchronous on the compute stream.                    */
+int rvll_allgather_theta(rvll_handle* h, int64_t B_local);
+int rvll_download_gathered_theta(rvll_handle* h, int64_t B_total, double* theta_all /*[B_total, ndim]*/);
 int rvll_comm_destroy(rvll_handle* h);
 
 /* ---- Keplerian curves at arbitrary times (post-processing helper) ------------------ */

@@ -93,6 +93,25 @@ def test_rccl_allgather_single_rank_and_sharded_wrapper(gpu_required):
         m.comm_destroy()
 
 
+def test_rccl_theta_gather_single_rank_cube_form(gpu_required):
+    """The cube form of the multi-GPU step on a one-rank RCCL communicator: theta produced on the device comes
+    back through rvll_allgather_theta next to the log-L gather; repeated steps keep the two collectives ordered."""
+    from evidence_amd.sharded import ShardedPriorLogLike
+    w = make_workload(3)
+    cubes = w.sample_cube(1000, seed=21)
+    with GpuRVModel(w.fixedpardict, w.table, w.parnames, priordict=w.priordict()) as m:
+        want_theta, want_logl = m.prior_loglike_batch(cubes)
+        m.comm_init(GpuRVModel.comm_unique_id(), 1, 0)
+        sharded = ShardedPriorLogLike(0, 1, model=m, transport="rccl")
+        for _ in range(4):
+            theta, logl = sharded(cubes)
+            assert np.array_equal(theta, want_theta) and np.array_equal(logl, want_logl)
+        m.comm_destroy()
+        from evidence_amd import RvllError
+        with pytest.raises(RvllError):
+            m.allgather_theta(10)                       # no communicator any more
+
+
 def test_reference_style_config_end_to_end(gpu_required):
     """examples/51peg/config_51peg.py (the reference's config-module format) -> read_config -> GpuRVModel:
     the BASELINE.md known answers for the shipped 51Peg example come out of the whole chain."""

@@ -68,3 +68,43 @@ def test_sharded_loglike_equals_serial(world, n):
         assert np.array_equal(out, serial)                       # every rank holds every log-L, in row order
         lo, hi = partition(n, world)[rank]
         assert calls == [hi - lo]                                # and evaluated only its own shard
+
+
+def _cube_worker(rank, world, port, n, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from evidence_amd.sharded import ShardedPriorLogLike
+        cubes = np.random.default_rng(7).random((n, 5))
+        calls = []
+        def evaluate(c):                                         # stands in for GpuRVModel.prior_loglike_batch
+            calls.append(len(c))
+            theta = 10.0 * c - 3.0
+            return theta, -0.5 * (theta ** 2).sum(axis=1)
+        theta, logl = ShardedPriorLogLike(rank, world, evaluate=evaluate, transport="dist")(cubes)
+        q.put((rank, theta, logl, calls))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 64), (2, 33), (3, 50)])
+def test_sharded_prior_loglike_returns_theta_and_logl_everywhere(world, n):
+    """The cube form: every rank transforms + evaluates its shard, then theta rows AND log-L are gathered."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cube_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    cubes = np.random.default_rng(7).random((n, 5))
+    theta = 10.0 * cubes - 3.0
+    logl = -0.5 * (theta ** 2).sum(axis=1)
+    for rank, th, ll, calls in results:
+        assert np.array_equal(th, theta) and np.array_equal(ll, logl)
+        assert calls == [padded_count(n, world)]                 # its own shard, padded to the common count
