@@ -95,6 +95,7 @@ PROTOTYPES = {
     "rvll_destroy": (C.c_int, [Handle]),
     "rvll_set_priors": (C.c_int, [Handle, C.POINTER(Prior), C.c_int32]),
     "rvll_prior_table_info": (C.c_int, [Handle, C.c_int32, _dp, _ip]),
+    "rvll_scalar_server": (C.c_int, [Handle, C.c_int32]),
     "rvll_loglike_batch": (C.c_int, [Handle, _dp, C.c_int64, _dp, _ip]),
     "rvll_prior_batch": (C.c_int, [Handle, _dp, C.c_int64, _dp]),
     "rvll_prior_loglike_batch": (C.c_int, [Handle, _dp, C.c_int64, _dp, _dp, _ip]),

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -171,6 +172,16 @@ struct rvll_handle {
     void* pin_in_dev = nullptr;      // device-visible aliases of the two pinned buffers (zero-copy path)
     void* pin_out_dev = nullptr;
 
+    // scalar-call server (rvll_scalar_server): persistent one-workgroup kernel + host-coherent control block
+    rvll::ServerCtl* srv = nullptr;             // pinned, mapped, coherent
+    rvll::ServerCtl* srv_dev = nullptr;         // its device address
+    hipStream_t srv_stream = nullptr;
+    bool srv_enabled = false, srv_running = false;
+    unsigned long long srv_seq = 0;             // request numbers (low 32 bits travel)
+    unsigned long long srv_last = 0;            // the last request word that was answered
+    double*  d_srv_out = nullptr;               // device-local {logL, flags} the server's tile writes
+    unsigned long long srv_idle_ticks = 500000; // 5 ms of the 100 MHz constant clock
+
     // geometry
     int pb_override = 0;
     std::unordered_map<long long, int> geo;     // batch size -> points per workgroup chosen for it
@@ -200,11 +211,26 @@ int sync_other_lanes(rvll_handle* h)
     return RVLL_OK;
 }
 
+// Ask a running scalar-call server to leave and wait for it.  Every entry point other than the scalar call
+// itself goes through use_device(), so the persistent kernel never coexists with allocations, frees or
+// collectives of its own handle (hipFree and friends synchronise the whole device).
+int server_stop(rvll_handle* h)
+{
+    if (!h->srv_running) return RVLL_OK;
+    const unsigned long long request = ((unsigned long long)rvll::kServerQuit << 32) | (unsigned)++h->srv_seq;
+    __atomic_store_n(&h->srv->request, request, __ATOMIC_RELEASE);
+    hipError_t e = hipStreamSynchronize(h->srv_stream);
+    h->srv_last = request;
+    h->srv_running = false;
+    if (e != hipSuccess) return fail(RVLL_E_HIP, "scalar server did not stop: %s", hipGetErrorString(e));
+    return RVLL_OK;
+}
+
 int use_device(rvll_handle* h)
 {
     if (!h) return fail(RVLL_E_INVALID, "null handle");
     HIP_TRY(hipSetDevice(h->device));
-    return RVLL_OK;
+    return server_stop(h);
 }
 
 bool slot_ok(const rvll_slot& s, int D) { return s.idx < D; }
@@ -469,6 +495,17 @@ int rvll_create(const rvll_layout* layout, const double* time, const double* vra
     CREATE_TRY(hipHostMalloc(&h->pin_out, rvll_handle::kPinBytes, hipHostMallocMapped));
     CREATE_TRY(hipHostGetDevicePointer(&h->pin_in_dev, h->pin_in, 0));
     CREATE_TRY(hipHostGetDevicePointer(&h->pin_out_dev, h->pin_out, 0));
+    {
+        void* p = nullptr;
+        CREATE_TRY(hipHostMalloc(&p, sizeof(rvll::ServerCtl), hipHostMallocMapped | hipHostMallocCoherent));
+        h->srv = new (p) rvll::ServerCtl();
+        void* pd = nullptr;
+        CREATE_TRY(hipHostGetDevicePointer(&pd, p, 0));
+        h->srv_dev = static_cast<rvll::ServerCtl*>(pd);
+        CREATE_TRY(hipStreamCreateWithFlags(&h->srv_stream, hipStreamNonBlocking));
+        CREATE_TRY(hipMalloc(&h->d_srv_out, 2 * sizeof(double)));
+        if (const char* e = getenv("RVLL_SCALAR_SERVER")) h->srv_enabled = atoi(e) != 0;
+    }
 
     const size_t nb = sizeof(double) * (size_t)n_epochs;
     std::vector<double> s2((size_t)n_epochs);
@@ -502,6 +539,7 @@ int rvll_destroy(rvll_handle* h)
 {
     if (!h) return RVLL_OK;
     (void)hipSetDevice(h->device);
+    if (h->srv) (void)server_stop(h);
     if (h->compute) (void)hipStreamSynchronize(h->compute);
     (void)sync_other_lanes(h);
     for (auto& c : h->nccl_comm) if (c && g_rccl.lib) { (void)g_rccl.CommDestroy(c); c = nullptr; }
@@ -511,6 +549,9 @@ int rvll_destroy(rvll_handle* h)
     dev_free(h->d_gather_theta);
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
+    if (h->srv_stream) (void)hipStreamDestroy(h->srv_stream);
+    if (h->srv) (void)hipHostFree(h->srv);
+    dev_free(h->d_srv_out);
     dev_free(h->d_t); dev_free(h->d_y); dev_free(h->d_s2); dev_free(h->d_inst); dev_free(h->d_linpar);
     dev_free(h->d_planets); dev_free(h->d_insts); dev_free(h->d_linslots);
     for (int l = 1; l < kMaxLanes; ++l) if (h->lanes[l]) (void)hipStreamDestroy(h->lanes[l]);
@@ -830,9 +871,91 @@ int rvll_dev_time_loglike(rvll_handle* h, int64_t B, int32_t warmup, int32_t ite
 }
 
 // ---- host-buffer hot calls -------------------------------------------------------
+}  // extern "C"
+
+namespace {
+
+int server_start(rvll_handle* h)
+{
+    HIP_TRY(hipSetDevice(h->device));
+    rvll::LoglikeArgs a;
+    int rc = build_args(h, h->srv_dev->theta, h->d_srv_out, reinterpret_cast<int32_t*>(h->d_srv_out + 1), 1, &a);
+    if (rc) return rc;
+    if (a.PB != 1) { a.PB = 1; a.CH = std::max(rvll::kThreads, std::min(h->chunk_items, h->Ne)); a.CH = (a.CH + 1) & ~1; }
+    if (h->have_priors) make_fused(h, h->srv_dev->theta, h->srv_dev->theta, &a);   // the prior op needs the tables
+    __atomic_store_n(&h->srv->state, rvll::kServerRunning, __ATOMIC_RELEASE);
+    HIP_TRY(rvll::launch_scalar_server(a, h->srv_dev, h->srv_last, h->srv_idle_ticks, h->srv_stream));
+    h->srv_running = true;
+    return RVLL_OK;
+}
+
+// One log-L through the persistent kernel: write theta and a new request number into the control block, spin on
+// the answer.  If the kernel left in the meantime (idle timeout) it is started again with the request pending.
+int scalar_call(rvll_handle* h, unsigned op, const double* theta, double* logL, int32_t* flags, double* theta_out)
+{
+    rvll::ServerCtl* c = h->srv;
+    if (h->srv_running && __atomic_load_n(&c->state, __ATOMIC_ACQUIRE) == rvll::kServerExited) {
+        HIP_TRY(hipStreamSynchronize(h->srv_stream));
+        h->srv_running = false;
+    }
+    if (!h->srv_running) {
+        HIP_TRY(hipSetDevice(h->device));
+        // the server reads the resident epoch table: anything still queued on the other streams goes first
+        HIP_TRY(hipStreamSynchronize(h->compute));
+        int rc = sync_other_lanes(h);
+        if (rc) return rc;
+    }
+    memcpy(c->theta, theta, sizeof(double) * (size_t)h->L.ndim);
+    const unsigned number = (unsigned)++h->srv_seq;
+    const unsigned long long request = ((unsigned long long)op << 32) | number;
+    __atomic_store_n(&c->request, request, __ATOMIC_RELEASE);
+    if (!h->srv_running) { int rc = server_start(h); if (rc) return rc; }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; ++spins) {
+        if (__atomic_load_n(&c->answer.number, __ATOMIC_ACQUIRE) == number) break;
+        __builtin_ia32_pause();
+        if ((spins & 0xfff) != 0xfff) continue;
+        if (__atomic_load_n(&c->state, __ATOMIC_ACQUIRE) == rvll::kServerExited &&
+            __atomic_load_n(&c->answer.number, __ATOMIC_ACQUIRE) != number) {
+            HIP_TRY(hipStreamSynchronize(h->srv_stream));           // left before it saw this request
+            h->srv_running = false;
+            int rc = server_start(h);
+            if (rc) return rc;
+        }
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+            (void)server_stop(h);
+            return fail(RVLL_E_HIP, "scalar server did not answer within 5 s");
+        }
+    }
+    h->srv_last = request;
+    if (op == rvll::kServerPrior) {
+        memcpy(theta_out, c->theta, sizeof(double) * (size_t)h->L.ndim);
+        return RVLL_OK;
+    }
+    if (logL) *logL = c->answer.logL;          // same 16-byte store as the number just seen
+    if (flags) *flags = c->answer.flags;
+    return RVLL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rvll_scalar_server(rvll_handle* h, int32_t enable)
+{
+    int rc = use_device(h);                   // also stops a running server
+    if (rc) return rc;
+    if (enable && h->L.ndim > rvll::kServerMaxDim)
+        return fail(RVLL_E_UNSUPPORTED, "scalar server supports up to %d parameters", rvll::kServerMaxDim);
+    h->srv_enabled = enable != 0;
+    return RVLL_OK;
+}
+
 int rvll_loglike_batch(rvll_handle* h, const double* theta, int64_t B, double* logL, int32_t* flags)
 {
     if (!h) return fail(RVLL_E_INVALID, "null handle");
+    if (B == 1 && h->srv_enabled && theta && logL)
+        return scalar_call(h, getenv("RVLL_SERVER_NOOP") ? rvll::kServerNoop : rvll::kServerLogLike, theta, logL, flags, nullptr);
     if (B < 0) return fail(RVLL_E_INVALID, "B < 0");
     if (B == 0) return use_device(h);
     if (!theta || !logL) return fail(RVLL_E_INVALID, "theta/logL is null");
@@ -895,6 +1018,7 @@ int rvll_prior_batch(rvll_handle* h, const double* cube, int64_t B, double* thet
     if (!h) return fail(RVLL_E_INVALID, "null handle");
     if (B < 0) return fail(RVLL_E_INVALID, "B < 0");
     if (h && !h->have_priors) return fail(RVLL_E_NOPRIORS, "rvll_set_priors has not been called");
+    if (B == 1 && h->srv_enabled && cube && theta) return scalar_call(h, rvll::kServerPrior, cube, nullptr, nullptr, theta);
     if (B == 0) return use_device(h);
     if (!cube || !theta) return fail(RVLL_E_INVALID, "cube/theta is null");
     int rc = rvll_dev_upload_cube(h, cube, B);

@@ -50,6 +50,28 @@ struct LoglikeArgs {
 };
 
 size_t loglike_lds_bytes(const LoglikeArgs& a);
+
+// ---- scalar-call server: a one-workgroup persistent kernel that answers single-point log-L requests through a
+// block of host-coherent pinned memory, so a scalar callback costs a PCIe round trip instead of a kernel launch
+// and a stream synchronisation.  Host and device share this layout; every field sits on its own cache line.
+constexpr int kServerMaxDim = 448;
+constexpr unsigned kServerRunning = 1u, kServerExited = 2u;
+constexpr unsigned kServerLogLike = 0u, kServerPrior = 1u, kServerNoop = 2u, kServerQuit = 3u;
+struct ServerAnswer { double logL; unsigned int number; int flags; };      // 16 bytes: leaves the GPU as ONE store
+struct ServerCtl {
+    alignas(64) unsigned long long request;   // host -> device, one 64-bit store: (op << 32) | request number;
+                                              // theta (or the cube row) is complete when it changes; op kServerQuit
+                                              // makes the kernel leave
+    alignas(64) unsigned int state;           // kServerRunning (host, before launch) / kServerExited (device, on exit)
+    alignas(64) ServerAnswer answer;          // device -> host: number == the request's number when logL/flags
+                                              // (and, for the prior op, theta) are complete
+    alignas(64) double theta[kServerMaxDim];
+};
+// a = arguments of a one-point launch whose theta points into *ctl (device address of the block) and whose
+// logL / flags point at device-local scratch; the kernel answers requests that differ from `last` and leaves
+// after idle_ticks (100 MHz) without one
+hipError_t launch_scalar_server(const LoglikeArgs& a, ServerCtl* ctl, unsigned long long last,
+                                unsigned long long idle_ticks, hipStream_t stream);
 hipError_t launch_loglike(const LoglikeArgs& a, hipStream_t stream);
 // resident 256-thread workgroups per CU for a given dynamic-LDS size (occupancy query)
 int loglike_blocks_per_cu(size_t lds_bytes);

@@ -27,7 +27,7 @@ namespace {
 
 constexpr double kTwoPi = 6.283185307179586476925286766559;   // fl(2*pi), as 2*np.pi
 
-__device__ __forceinline__ double slot_get(const rvll_slot& s, const double* th)
+__device__ __forceinline__ double slot_get(const rvll_slot s, const double* th)
 {
     return s.idx >= 0 ? th[s.idx] : s.val;
 }
@@ -289,12 +289,11 @@ __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx&
     }
 }
 
-// 4 workgroups of 256 per CU (4 waves/SIMD): caps the kernel at 128 VGPRs
+// One tile of live points [p0, p0 + npts) by one 256-thread workgroup: stage, decode, items, reduce, write.
+// Shared by the batch kernel (tile = blockIdx) and the scalar-call server (one point per request).
 template <int PREC, bool FUSED>
-__global__ __launch_bounds__(kThreads, 4) __attribute__((flatten))      // flatten: the prior routines of the fused
-void loglike_kernel(const LoglikeArgs a)                                // form must live under the same VGPR cap
+__device__ __forceinline__ __attribute__((flatten)) void loglike_tile(const LoglikeArgs& __restrict__ a, double* __restrict__ smem, long long p0, int npts)
 {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
     const Carve cv = carve(a.PB, a.D, a.Np, a.Ni, a.nlin, a.CH);
     double* theta_s = smem + cv.theta;
     double* pp      = smem + cv.pp;
@@ -312,9 +311,6 @@ void loglike_kernel(const LoglikeArgs a)                                // form 
     const int tid  = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = tid >> 6;
-    const long long p0 = (long long)blockIdx.x * a.PB;
-    const int npts = (int)min((long long)a.PB, a.B - p0);
-    if (npts <= 0) return;
 
     // 1. stage this block's theta rows (one contiguous, coalesced span) + init.  Fused form: the rows are
     //    unit-cube coordinates and go through the prior transform on the way in (light kinds element by
@@ -460,6 +456,79 @@ void loglike_kernel(const LoglikeArgs a)                                // form 
         a.logL[p0 + pl] = invalid ? -1e30 : a.cte - acc[pl];              // rvmodel:203, :78-80
         if (a.flags) a.flags[p0 + pl] = f;
     }
+}
+
+// 4 workgroups of 256 per CU (4 waves/SIMD): caps the kernel at 128 VGPRs
+template <int PREC, bool FUSED>
+__global__ __launch_bounds__(kThreads, 4) __attribute__((flatten))      // flatten: the prior routines of the fused
+void loglike_kernel(const LoglikeArgs a)                                // form must live under the same VGPR cap
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const long long p0 = (long long)blockIdx.x * a.PB;
+    const int npts = (int)min((long long)a.PB, a.B - p0);
+    if (npts <= 0) return;
+    loglike_tile<PREC, FUSED>(a, smem, p0, npts);
+}
+
+// Scalar-call server (rvll_kernels.h, ServerCtl).  Thread 0 polls the request word in host memory (system-scope
+// acquire; one PCIe read per poll — op and number travel in that one word), the workgroup evaluates the one
+// point exactly as a one-point launch would (same loglike_tile, same bits) into device-local scratch, and
+// thread 0 sends log-L, flags and the request number back as ONE 16-byte store, so the host needs no second
+// flag and the GPU no fence between result and flag.  Every wave leaves through the same uniform test: a quit
+// request, or idle_ticks of the constant 100 MHz clock without a request — so the kernel ends by itself if the
+// host stops asking, whatever the reason (the quit request is just another op in the same word).
+template <int PREC>
+__global__ __launch_bounds__(kThreads, 1) __attribute__((flatten))     // one workgroup on the chip: no VGPR cap
+void scalar_server_kernel(const LoglikeArgs a, ServerCtl* ctl, unsigned long long last, unsigned long long idle_ticks)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const Carve cv = carve(a.PB, a.D, a.Np, a.Ni, a.nlin, a.CH);
+    unsigned long long* word = reinterpret_cast<unsigned long long*>(smem + cv.total_doubles);   // [0] request, [1] stop
+    for (;;) {
+        if (threadIdx.x == 0) {
+            const unsigned long long t0 = wall_clock64();
+            unsigned long long r, stop = 0;
+            for (unsigned polls = 1;; ++polls) {      // one PCIe read per poll; the clock only every 64 polls
+                r = __hip_atomic_load(&ctl->request, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (r != last) { stop = (unsigned)(r >> 32) == kServerQuit; break; }
+                if ((polls & 63u) == 0u && wall_clock64() - t0 > idle_ticks) { stop = 1; break; }
+            }
+            word[0] = r;
+            word[1] = stop;
+        }
+        __syncthreads();
+        const unsigned long long r = word[0];
+        if (word[1] != 0) break;
+        const unsigned op = (unsigned)(r >> 32);
+        ServerAnswer ans{0., (unsigned)r, 0};
+        if (op == kServerPrior) {
+            // prior(cube): the row is transformed in place (staged through LDS first: the sorted kinds read
+            // the whole row).  a.priors is null until rvll_set_priors; the host does not send the op before.
+            double* row = smem;
+            for (int d = threadIdx.x; d < a.D; d += kThreads) row[d] = ctl->theta[d];
+            __syncthreads();
+            for (int d = threadIdx.x; d < a.D; d += kThreads)
+                ctl->theta[d] = prior_is_heavy(a.priors[d].kind) ? prior_heavy(a.priors[d], row[d])
+                                                                 : prior_light(a.priors, a.D, row, d);
+            __threadfence_system();                   // every thread's theta stores are out before the answer
+            __syncthreads();
+        } else if (op == kServerLogLike) {
+            loglike_tile<PREC, false>(a, smem, 0, 1);
+            if (threadIdx.x == 0) {                   // thread 0 wrote a.logL[0] / a.flags[0] itself
+                ans.logL = __hip_atomic_load(a.logL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ans.flags = __hip_atomic_load(a.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }                                             // any other op: acknowledged only (round-trip probe)
+        if (threadIdx.x == 0) {
+            static_assert(sizeof(ServerAnswer) == 16, "the answer must leave as one 16-byte store");
+            typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+            // volatile: emitted with system-scope cache bits (sc0 sc1), i.e. written through to host memory
+            *reinterpret_cast<volatile u64x2*>(&ctl->answer) = __builtin_bit_cast(u64x2, ans);
+        }
+        last = r;
+        __syncthreads();                              // the LDS words and stage are reused by the next request
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(&ctl->state, kServerExited, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---------------------------------------------------------------------------
@@ -664,6 +733,20 @@ hipError_t launch_loglike(const LoglikeArgs& a, hipStream_t stream)
     case RVLL_PREC_MIXED: hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_MIXED, false>), grid, block, lds, stream, a); break;
     case RVLL_PREC_FP32:  hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP32, false>), grid, block, lds, stream, a); break;
     default:              hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP64, false>), grid, block, lds, stream, a); break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_scalar_server(const LoglikeArgs& a, ServerCtl* ctl, unsigned long long last,
+                                unsigned long long idle_ticks, hipStream_t stream)
+{
+    if (a.B != 1 || a.PB != 1 || !ctl || a.D > kServerMaxDim) return hipErrorInvalidValue;
+    const size_t lds = loglike_lds_bytes(a) + 2 * sizeof(unsigned long long);
+    const dim3 grid(1), block(kThreads);
+    switch (a.precision) {
+    case RVLL_PREC_MIXED: hipLaunchKernelGGL((scalar_server_kernel<RVLL_PREC_MIXED>), grid, block, lds, stream, a, ctl, last, idle_ticks); break;
+    case RVLL_PREC_FP32:  hipLaunchKernelGGL((scalar_server_kernel<RVLL_PREC_FP32>), grid, block, lds, stream, a, ctl, last, idle_ticks); break;
+    default:              hipLaunchKernelGGL((scalar_server_kernel<RVLL_PREC_FP64>), grid, block, lds, stream, a, ctl, last, idle_ticks); break;
     }
     return hipGetLastError();
 }

@@ -73,6 +73,13 @@ class GpuRVModel:
             C.byref(layout_c), _abi.as_dp(self.table.time), _abi.as_dp(self.table.vrad),
             _abi.as_dp(self.table.svrad), _abi.as_ip(self.table.inst_id), self.table.n_epochs,
             _abi.as_dp(series) if series is not None else None, int(device), C.byref(self._h)))
+        # persistent buffers (and their ctypes pointers) of the scalar callbacks: per call only the copy of x
+        # and one foreign call remain on the Python side
+        nd = max(1, self.ndim)
+        self._s_in, self._s_th = np.empty((1, nd)), np.empty((1, nd))
+        self._s_out, self._s_flag = np.empty(1), np.zeros(1, dtype=np.int32)
+        self._s_in_p, self._s_th_p = _abi.as_dp(self._s_in), _abi.as_dp(self._s_th)
+        self._s_out_p, self._s_flag_p = _abi.as_dp(self._s_out), _abi.as_ip(self._s_flag)
         self.priordict = None
         if priordict is not None:
             self.set_priors(priordict)
@@ -131,8 +138,14 @@ class GpuRVModel:
 
     def log_likelihood(self, x):
         """Scalar form, same signature as RVModel.log_likelihood (rvmodel/__init__.py:157)."""
-        x = np.asarray(x, dtype=np.float64).reshape(1, -1)
-        return float(self.log_likelihood_batch(x)[0])
+        x = np.asarray(x, dtype=np.float64)
+        if x.size != self.ndim:
+            raise ValueError(f"expected {self.ndim} parameters, got {x.size}")
+        self._s_in[0, :self.ndim] = x.ravel()
+        rc = self._lib.rvll_loglike_batch(self._h, self._s_in_p, 1, self._s_out_p, self._s_flag_p)
+        if rc:
+            _abi.check(rc)
+        return float(self._s_out[0])
 
     # ---- Keplerian curves for post-processing -----------------------------------------------------
     def _curves(self, X, time, mask):
@@ -168,7 +181,13 @@ class GpuRVModel:
 
     def prior_transform(self, cube):
         cube = np.asarray(cube, dtype=np.float64)
-        return self.prior_transform_batch(cube.reshape(1, -1))[0].reshape(cube.shape)
+        if cube.size != self.ndim:
+            raise ValueError(f"expected {self.ndim} coordinates, got {cube.size}")
+        self._s_in[0, :self.ndim] = cube.ravel()
+        rc = self._lib.rvll_prior_batch(self._h, self._s_in_p, 1, self._s_th_p)
+        if rc:
+            _abi.check(rc)
+        return self._s_th[0, :self.ndim].copy().reshape(cube.shape)
 
     def prior_loglike_batch(self, cubes, return_flags=False):
         """Fused prior(cube) -> theta -> log-L: one upload, two launches, one download."""
@@ -201,6 +220,12 @@ class GpuRVModel:
 
     def dev_loglike(self, n):
         _abi.check(self._lib.rvll_dev_loglike(self._h, int(n)))
+
+    def scalar_server(self, enable=True):
+        """Answer scalar log_likelihood(x) calls through a persistent kernel polling pinned host memory (a PCIe
+        round trip instead of a launch + synchronisation; same bits).  Any other call on this model stops the
+        kernel first; it also leaves by itself after 5 ms without a request and restarts on the next one."""
+        _abi.check(self._lib.rvll_scalar_server(self._h, 1 if enable else 0))
 
     def prior_table_info(self):
         """{parameter: (measured interpolation error, evaluated-by-interpolation flag)} for the Beta/Gamma priors."""

@@ -214,6 +214,16 @@ int rvll_prior_batch(rvll_handle* h, const double* cube, int64_t B, double* thet
 int rvll_prior_loglike_batch(rvll_handle* h, const double* cube, int64_t B,
                              double* theta_out, double* logL, int32_t* flags);
 
+/* ---- scalar-callback latency ------------------------------------------------------------------------- */
+/* PolyChord's loglike(theta) is irreducibly scalar (evidence/polychord/__init__.py:166-171): one theta per call.
+ * With the server enabled, rvll_loglike_batch(B = 1) is answered by a persistent one-workgroup kernel that polls
+ * a block of host-coherent pinned memory: the call writes theta and a request number there and spins on the
+ * answer — a PCIe round trip instead of a kernel launch plus a stream synchronisation, same bits.  The kernel
+ * leaves by itself after 5 ms without a request and is restarted by the next scalar call; every other entry point
+ * of the handle stops it first.  enable = 0 turns it off (default; RVLL_SCALAR_SERVER=1 in the environment turns
+ * it on at rvll_create).                                                                                    */
+int rvll_scalar_server(rvll_handle* h, int32_t enable);
+
 /* ---- device-resident forms (no PCIe inside; used by bench and multi-GPU) -- */
 /* Reserve device buffers for up to B points and copy theta (or cube) in.     */
 int rvll_dev_reserve(rvll_handle* h, int64_t B);

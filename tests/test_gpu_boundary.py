@@ -237,3 +237,53 @@ def test_large_host_batches_go_up_in_overlapped_chunks(gpu_required, n, monkeypa
         monkeypatch.setenv("RVLL_SPLIT", "7")
         seven = m.log_likelihood_batch(theta)
     assert np.array_equal(got, whole) and np.array_equal(flags, flags1) and np.array_equal(seven, whole)
+
+
+def test_scalar_server_answers_polychord_style_calls(gpu_required):
+    """The persistent scalar-call kernel (rvll_scalar_server): same bits as the launch-per-call path, flags
+    included; survives interleaved batch / prior calls (each stops it), its own idle exit, a second model with
+    its own server, and destruction while running."""
+    import time
+    case = golden.config_case(3)
+    bad = case.theta[5].copy()
+    bad[case.parnames.index("planet1_period")] = np.nan
+    with GpuRVModel(case.fixed, case.table, case.parnames) as m, \
+         GpuRVModel(case.fixed, case.table, case.parnames) as m2:
+        want = m.log_likelihood_batch(case.theta)
+        m.scalar_server(True)
+        m2.scalar_server(True)
+        got = np.array([m.log_likelihood(x) for x in case.theta[:64]])
+        assert np.array_equal(got, want[:64])
+        assert np.array_equal(np.array([m2.log_likelihood(x) for x in case.theta[64:96]]), want[64:96])
+        # a batch call in between stops the server; the next scalar call starts it again
+        assert np.array_equal(m.log_likelihood_batch(case.theta[:300]), want[:300])
+        assert m.log_likelihood(case.theta[7]) == want[7]
+        one, flag = m.log_likelihood_batch(case.theta[9:10], return_flags=True)
+        assert one[0] == want[9] and flag[0] == 0
+        # idle exit (5 ms without a request), then restart on demand
+        time.sleep(0.05)
+        assert m.log_likelihood(case.theta[11]) == want[11]
+        # non-finite input behaves as in the launch path
+        m.scalar_server(False)
+        ref_bad = m.log_likelihood(bad)
+        m.scalar_server(True)
+        got_bad = m.log_likelihood(bad)
+        assert (np.isnan(ref_bad) and np.isnan(got_bad)) or ref_bad == got_bad
+        # PolyChord-convention closure on top of it
+        prior, loglike, ndim, nderived = make_polychord_callbacks(m)
+        val, derived = loglike(case.theta[3])
+        assert val == want[3] and derived == []
+    # prior(cube) and loglike(theta) alternate per point, as PolyChord calls them: both go through the server
+    w = make_workload(3)
+    cubes = w.sample_cube(40, seed=4)
+    with GpuRVModel(w.fixedpardict, w.table, w.parnames, priordict=w.priordict()) as m:
+        th_want, ll_want = m.prior_loglike_batch(cubes)
+        m.scalar_server(True)
+        prior, loglike, ndim, nderived = make_polychord_callbacks(m)
+        for c, th_w, ll_w in zip(cubes, th_want, ll_want):
+            th = prior(c)
+            assert np.array_equal(th, th_w)
+            assert loglike(th)[0] == ll_w
+    # both handles were destroyed with their servers possibly still polling: a new model works at once
+    with GpuRVModel(case.fixed, case.table, case.parnames) as m3:
+        assert np.array_equal(m3.log_likelihood_batch(case.theta[:10]), want[:10])
