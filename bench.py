@@ -375,6 +375,20 @@ def main():
             model.dev_sync()
             out["prior_plus_loglike_one_launch_evals_per_s"] = 50 * B / (time.perf_counter() - t1)
             model.dev_upload_theta(theta)
+            # scalar callback latency (PolyChord's form: one theta per call): launch + sync vs the persistent kernel
+            x0 = theta[0]
+            lat = {}
+            for mode in ("launch", "server"):
+                model.scalar_server(mode == "server")
+                for _ in range(50):
+                    model.log_likelihood(x0)
+                t1 = time.perf_counter()
+                for _ in range(1000):
+                    model.log_likelihood(x0)
+                lat[mode] = (time.perf_counter() - t1) / 1000 * 1e6
+            model.scalar_server(False)
+            out["scalar_call_us"] = {"launch_per_call": lat["launch"], "persistent_kernel": lat["server"]}
+            model.dev_upload_theta(theta)
             out["fip_periodogram"] = fip_extra(not args.no_cpu)
         if not args.no_cpu and world == 1:
             cpu, perr, mean_it = cpu_baseline(w, model.layout, theta, gpu_logl, args.cpu_seconds)
