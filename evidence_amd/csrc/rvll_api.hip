@@ -1,8 +1,8 @@
 // rvll_api.hip — host side of the C-ABI declared in include/rvll.h.
 //
-// One handle = one device + two HIP streams (compute, comm) + resident epoch
-// table, layout and batch buffers.  No PyTorch, no other runtime: plain HIP, and
-// RCCL (loaded lazily with dlopen) for the multi-GPU all-gather.
+// One handle = one device + its streams (compute = pipeline lane 0, further lanes for the multi-GPU step, one
+// for the scalar-call server) + resident epoch table, layout, prior tables and batch buffers.  No PyTorch, no
+// other runtime: plain HIP, and RCCL (loaded lazily with dlopen) for the multi-GPU all-gathers.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <algorithm>
@@ -27,14 +27,20 @@ namespace {
 
 thread_local std::string g_last_error;
 
-int fail(int code, const char* fmt, ...)
+int vfail(int code, const char* fmt, va_list ap)
 {
     char buf[1024];
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    g_last_error = buf;
+    return code;
+}
+
+int fail(int code, const char* fmt, ...)
+{
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
+    code = vfail(code, fmt, ap);
     va_end(ap);
-    g_last_error = buf;
     return code;
 }
 
@@ -44,12 +50,10 @@ int fail(int code, const char* fmt, ...)
 namespace rvll {
 int report_error(int code, const char* fmt, ...)
 {
-    char buf[1024];
     va_list ap;
     va_start(ap, fmt);
-    vsnprintf(buf, sizeof buf, fmt, ap);
+    code = vfail(code, fmt, ap);
     va_end(ap);
-    g_last_error = buf;
     return code;
 }
 }  // namespace rvll

@@ -221,7 +221,9 @@ int rvll_prior_loglike_batch(rvll_handle* h, const double* cube, int64_t B,
  * answer — a PCIe round trip instead of a kernel launch plus a stream synchronisation, same bits.  The kernel
  * leaves by itself after 5 ms without a request and is restarted by the next scalar call; every other entry point
  * of the handle stops it first.  enable = 0 turns it off (default; RVLL_SCALAR_SERVER=1 in the environment turns
- * it on at rvll_create).                                                                                    */
+ * it on at rvll_create).  While it runs, calls that synchronise the whole device (hipMalloc / hipFree, also of
+ * other handles in the process) wait until it is idle, i.e. at most the 5 ms, provided no other thread keeps
+ * feeding it meanwhile.                                                                                      */
 int rvll_scalar_server(rvll_handle* h, int32_t enable);
 
 /* ---- device-resident forms (no PCIe inside; used by bench and multi-GPU) -- */
