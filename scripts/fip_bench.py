@@ -18,6 +18,7 @@ ap.add_argument("--pmin", type=float, default=1.5)
 ap.add_argument("--pmax", type=float, default=1000.0)
 ap.add_argument("--repeats", type=int, default=20)
 ap.add_argument("--no-cpu", action="store_true")
+ap.add_argument("--peak-frac", type=float, default=0.8, help="fraction of the samples sitting on the posterior peaks")
 args = ap.parse_args()
 
 rng = np.random.default_rng(2021)
@@ -28,7 +29,7 @@ for r in range(args.runs):
     for k in range(1, args.nmod):
         n = args.samples
         s = np.exp(rng.uniform(np.log(args.pmin), np.log(args.pmax), (n, k)))
-        s = np.where(rng.random((n, k)) < 0.8, peaks[:k] * np.exp(rng.normal(0, 5e-4, (n, k))), s)
+        s = np.where(rng.random((n, k)) < args.peak_frac, peaks[:k] * np.exp(rng.normal(0, 5e-4, (n, k))), s)
         per_k.append((s, rng.gamma(0.5, 1.0, n)))
     post.append(per_k)
 pky = rng.dirichlet(np.ones(args.nmod))
