@@ -186,6 +186,12 @@ struct rvll_handle {
     double*  d_srv_out = nullptr;               // device-local {logL, flags} the server's tile writes
     unsigned long long srv_idle_ticks = 500000; // 5 ms of the 100 MHz constant clock
 
+    // device-resident slice-sampling walk (rvll_slice_walk)
+    long long walk_cap = 0;                     // rows
+    double *d_walk_u = nullptr, *d_walk_theta = nullptr, *d_walk_logl = nullptr, *d_walk_chol = nullptr;
+    int32_t* d_walk_wrapped = nullptr;
+    unsigned long long* d_walk_ncalls = nullptr;
+
     // geometry
     int pb_override = 0;
     std::unordered_map<long long, int> geo;     // batch size -> points per workgroup chosen for it
@@ -556,6 +562,8 @@ int rvll_destroy(rvll_handle* h)
     if (h->srv_stream) (void)hipStreamDestroy(h->srv_stream);
     if (h->srv) (void)hipHostFree(h->srv);
     dev_free(h->d_srv_out);
+    dev_free(h->d_walk_u); dev_free(h->d_walk_theta); dev_free(h->d_walk_logl); dev_free(h->d_walk_chol);
+    dev_free(h->d_walk_wrapped); dev_free(h->d_walk_ncalls);
     dev_free(h->d_t); dev_free(h->d_y); dev_free(h->d_s2); dev_free(h->d_inst); dev_free(h->d_linpar);
     dev_free(h->d_planets); dev_free(h->d_insts); dev_free(h->d_linslots);
     for (int l = 1; l < kMaxLanes; ++l) if (h->lanes[l]) (void)hipStreamDestroy(h->lanes[l]);
@@ -1082,6 +1090,78 @@ int rvll_prior_loglike_batch(rvll_handle* h, const double* cube, int64_t B,
         if (rc) return rc;
     }
     return rvll_dev_download(h, B, theta_out, logL, flags);
+}
+
+// ---- device-resident slice-sampling walk ---------------------------------------------------------------
+int rvll_slice_walk(rvll_handle* h, double* cube, double* theta, double* logl, int64_t K, double lstar,
+                    const double* chol, const int32_t* wrapped, int32_t nsteps, int32_t max_rounds,
+                    uint64_t seed, int64_t* ncalls)
+{
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!h->have_priors) return fail(RVLL_E_NOPRIORS, "rvll_set_priors has not been called");
+    if (K < 0 || nsteps < 0) return fail(RVLL_E_INVALID, "negative size");
+    if (ncalls) *ncalls = 0;
+    if (K == 0 || nsteps == 0) return RVLL_OK;
+    if (!cube || !theta || !logl || !chol) return fail(RVLL_E_INVALID, "null buffer");
+    if (max_rounds < 1 || max_rounds > 4096 || nsteps >= (1 << 18) || K >= (1LL << 31))
+        return fail(RVLL_E_INVALID, "nsteps / max_rounds / K out of range");
+    const size_t D = (size_t)h->L.ndim;
+    if (D < 1) return fail(RVLL_E_INVALID, "no free parameter to walk in");
+    rc = rvll_dev_reserve(h, K);                       // scratch rows: d_cube, d_theta, log-L / flags of lane 0
+    if (rc) return rc;
+    rc = sync_other_lanes(h);
+    if (rc) return rc;
+    if (K > h->walk_cap || !h->d_walk_chol) {
+        HIP_TRY(hipStreamSynchronize(h->compute));
+        dev_free(h->d_walk_u); dev_free(h->d_walk_theta); dev_free(h->d_walk_logl);
+        h->walk_cap = 0;
+        const size_t cap = (size_t)std::max<long long>(K, 1024);
+        HIP_TRY(hipMalloc(&h->d_walk_u, sizeof(double) * D * cap));
+        HIP_TRY(hipMalloc(&h->d_walk_theta, sizeof(double) * D * cap));
+        HIP_TRY(hipMalloc(&h->d_walk_logl, sizeof(double) * cap));
+        if (!h->d_walk_chol) {
+            HIP_TRY(hipMalloc(&h->d_walk_chol, sizeof(double) * D * D));
+            HIP_TRY(hipMalloc(&h->d_walk_wrapped, sizeof(int32_t) * D));
+            HIP_TRY(hipMalloc(&h->d_walk_ncalls, sizeof(unsigned long long)));
+        }
+        h->walk_cap = (long long)cap;
+    }
+    std::vector<int32_t> wr(D, 0);
+    if (wrapped) for (size_t k = 0; k < D; ++k) wr[k] = wrapped[k] != 0;
+    hipStream_t st = h->compute;
+    HIP_TRY(hipMemcpyAsync(h->d_walk_u, cube, sizeof(double) * D * (size_t)K, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(h->d_walk_theta, theta, sizeof(double) * D * (size_t)K, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(h->d_walk_logl, logl, sizeof(double) * (size_t)K, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(h->d_walk_chol, chol, sizeof(double) * D * D, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(h->d_walk_wrapped, wr.data(), sizeof(int32_t) * D, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(h->d_walk_ncalls, 0, sizeof(unsigned long long), st));
+    HIP_TRY(hipStreamSynchronize(st));                 // wr (and pageable sources) may go out of scope
+
+    rvll::LoglikeArgs a;
+    rc = build_args(h, h->d_theta, h->d_logL2[0], h->d_flags2[0], K, &a);
+    if (rc) return rc;
+    make_fused(h, h->d_cube, h->d_theta, &a);
+    // the walk keeps per-walker state in LDS next to the tile's carve: shrink the group until both fit
+    while (a.PB > 1 && (rvll::walk_lds_bytes(a) > 60 * 1024 || (long long)a.PB * a.D > 4 * rvll::kThreads)) {
+        a.PB -= 1;
+        a.CH = std::min(h->chunk_items, std::max(rvll::kThreads, a.PB * h->Ne));
+        a.CH = (a.CH + 1) & ~1;
+    }
+    if (rvll::walk_lds_bytes(a) > 64 * 1024 || (long long)a.PB * a.D > 4 * rvll::kThreads)
+        return fail(RVLL_E_UNSUPPORTED, "%d parameters exceed the walk kernel's LDS budget", a.D);
+    rvll::WalkArgs w{h->d_walk_u, h->d_walk_theta, h->d_walk_logl, h->d_walk_chol, h->d_walk_wrapped, (long long)K,
+                     nsteps, max_rounds, (unsigned long long)seed, lstar, h->d_walk_ncalls};
+    HIP_TRY(rvll::launch_slice_walk(a, w, st));
+    unsigned long long n = 0;
+    HIP_TRY(hipMemcpyAsync(cube, h->d_walk_u, sizeof(double) * D * (size_t)K, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(theta, h->d_walk_theta, sizeof(double) * D * (size_t)K, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(logl, h->d_walk_logl, sizeof(double) * (size_t)K, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&n, h->d_walk_ncalls, sizeof n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (ncalls) *ncalls = (int64_t)n;
+    h->theta_async = false;
+    return RVLL_OK;
 }
 
 // ---- Keplerian curves (post-processing helper) ------------------------------------------------------

@@ -51,6 +51,28 @@ struct LoglikeArgs {
 
 size_t loglike_lds_bytes(const LoglikeArgs& a);
 
+// ---- device-resident slice-sampling walk (the proposal step of nested sampling; evidence_amd/nested.py) -------
+// K walkers start at cube points u (log-L above lstar) and take nsteps hit-and-run slice moves inside the region
+// logL > lstar of the unit cube: direction = chol * normal / norm, chord limited by the cube walls (circular
+// `wrapped` parameters: half a turn), candidate = uniform point of the chord, prior transform + log-L, accept if
+// logL > lstar, otherwise shrink the chord towards the current point — up to max_rounds times per move.
+// One workgroup owns a.PB walkers for the whole walk and evaluates its active candidates with loglike_tile.
+struct WalkArgs {
+    double* u;                 // [K, D] in: start, out: end positions
+    double* theta;             // [K, D] in: theta of the start points, out: theta of the end points
+    double* logl;              // [K]    in/out likewise
+    const double* chol;        // [D, D] row-major lower-triangular whitening factor
+    const int32_t* wrapped;    // [D] 1 = circular parameter
+    long long K;
+    int nsteps, max_rounds;
+    unsigned long long seed;
+    double lstar;
+    unsigned long long* ncalls;   // += likelihood evaluations
+};
+size_t walk_lds_bytes(const LoglikeArgs& a);
+// a: fused (cube -> theta -> log-L) arguments whose cube / theta_out / logL / flags rows [0, K) are scratch
+hipError_t launch_slice_walk(const LoglikeArgs& a, const WalkArgs& w, hipStream_t stream);
+
 // ---- scalar-call server: a one-workgroup persistent kernel that answers single-point log-L requests through a
 // block of host-coherent pinned memory, so a scalar callback costs a PCIe round trip instead of a kernel launch
 // and a stream synchronisation.  Host and device share this layout; every field sits on its own cache line.

@@ -470,6 +470,138 @@ void loglike_kernel(const LoglikeArgs a)                                // form 
     loglike_tile<PREC, FUSED>(a, smem, p0, npts);
 }
 
+// Device-resident slice-sampling walk (rvll_kernels.h, WalkArgs; the scheme of evidence_amd/nested.py
+// run_nested_slice, which follows the reference's UltraNest wrapper: region slice sampling, nsteps moves per new
+// point, circular omega / ml0 — evidence/ultranest/__init__.py:159-175).  Everything a move needs stays on the
+// chip: counter-based random numbers, directions, chords, candidates (written to the workgroup's scratch rows),
+// prior transform + log-L of the active candidates through the same loglike_tile as every other path, accept /
+// shrink.  Loops are bounded by nsteps * max_rounds; all waves run the same trip counts (the active count is
+// shared through LDS).
+template <int PREC>
+__global__ __launch_bounds__(kThreads, 2) __attribute__((flatten))      // 256 VGPRs: prior routines + tile in one loop nest
+void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const Carve cv = carve(a.PB, a.D, a.Np, a.Ni, a.nlin, a.CH);
+    const int D = a.D, PB = a.PB, tid = threadIdx.x;
+    const long long w0 = (long long)blockIdx.x * PB;
+    const int nw = (int)min((long long)PB, w.K - w0);
+    if (nw <= 0) return;
+    double* wu   = smem + ((cv.total_doubles + 1) & ~1);   // [PB][D] current positions
+    double* dir  = wu + PB * D;                            // [PB][D] normals, then unit directions
+    double* tmin = dir + PB * D;                           // [PB]
+    double* tmax = tmin + PB;
+    double* tcur = tmax + PB;
+    double* wl   = tcur + PB;
+    int* act     = reinterpret_cast<int*>(wl + PB);         // [PB] active walkers (local index), compacted
+    int* accepted = act + PB;                               // [PB]
+    int* nact_s  = accepted + PB;                           // [1]
+    const double one_below = 0.99999999999999988898;        // nextafter(1, 0)
+
+    for (int i = tid; i < nw * D; i += kThreads) wu[i] = w.u[w0 * D + i];
+    for (int i = tid; i < nw; i += kThreads) wl[i] = w.logl[w0 + i];
+    unsigned long long calls = 0;                           // thread 0 only
+    __syncthreads();
+
+    for (int step = 0; step < w.nsteps; ++step) {
+        // standard normals (Box-Muller on two counter-based uniforms)
+        for (int i = tid; i < nw * D; i += kThreads) {
+            const int pl = i / D, k = i - pl * D;
+            const unsigned long long ctr = ((unsigned long long)(w0 + pl) << 32) | ((unsigned long long)step << 14) | (unsigned)(2 * k);
+            const double u1 = uniform01(w.seed, ctr), u2 = uniform01(w.seed, ctr + 1);
+            double sn, cs;
+            sincos_f64(kTwoPi * u2, sn, cs);
+            dir[i] = sqrt(-2. * log(1. - u1)) * cs;
+        }
+        __syncthreads();
+        // direction = chol * z (lower triangular), into tcur-free scratch: reuse the candidate rows in registers
+        double mine[4];                                     // up to 4 elements per thread (PB * D <= 1024)
+        int cnt = 0;
+        for (int i = tid; i < nw * D; i += kThreads) {
+            const int pl = i / D, k = i - pl * D;
+            double acc = 0.;
+            for (int j = 0; j <= k; ++j) acc += w.chol[k * D + j] * dir[pl * D + j];
+            mine[cnt++ & 3] = acc;
+        }
+        __syncthreads();
+        cnt = 0;
+        for (int i = tid; i < nw * D; i += kThreads) dir[i] = mine[cnt++ & 3];
+        __syncthreads();
+        // one thread per walker: normalise, chord, activate
+        for (int pl = tid; pl < nw; pl += kThreads) {
+            double n2 = 0.;
+            for (int k = 0; k < D; ++k) n2 += dir[pl * D + k] * dir[pl * D + k];
+            const double inv = 1. / sqrt(n2);
+            double lo = -INFINITY, hi = INFINITY;
+            for (int k = 0; k < D; ++k) {
+                const double d = dir[pl * D + k] * inv, u = wu[pl * D + k];
+                dir[pl * D + k] = d;
+                if (d == 0.) continue;
+                if (w.wrapped[k]) {
+                    const double half = 0.5 / fabs(d);
+                    lo = fmax(lo, -half); hi = fmin(hi, half);
+                } else {
+                    const double t0 = (0. - u) / d, t1 = (1. - u) / d;
+                    lo = fmax(lo, fmin(t0, t1)); hi = fmin(hi, fmax(t0, t1));
+                }
+            }
+            tmin[pl] = lo; tmax[pl] = hi;
+            act[pl] = pl;
+        }
+        if (tid == 0) nact_s[0] = nw;
+        __syncthreads();
+
+        for (int round = 0; round < w.max_rounds; ++round) {
+            const int nact = nact_s[0];
+            if (nact == 0) break;
+            for (int ai = tid; ai < nact; ai += kThreads) {
+                const int pl = act[ai];
+                const unsigned long long ctr = ((unsigned long long)(w0 + pl) << 32) | ((unsigned long long)step << 14) |
+                                               (unsigned)(8192 + round);
+                tcur[pl] = tmin[pl] + (tmax[pl] - tmin[pl]) * uniform01(w.seed, ctr);
+                accepted[pl] = 0;
+            }
+            __syncthreads();
+            double* crow = const_cast<double*>(a.cube) + w0 * D;       // this workgroup's scratch rows
+            for (int i = tid; i < nact * D; i += kThreads) {
+                const int ai = i / D, k = i - ai * D, pl = act[ai];
+                double c = wu[pl * D + k] + tcur[pl] * dir[pl * D + k];
+                if (w.wrapped[k]) c -= floor(c);
+                crow[ai * D + k] = fmin(fmax(c, 0.), one_below);
+            }
+            __syncthreads();
+            loglike_tile<PREC, true>(a, smem, w0, nact);               // prior transform + log-L of the candidates
+            __syncthreads();
+            for (int ai = tid; ai < nact; ai += kThreads) {
+                const int pl = act[ai];
+                const double cl = a.logL[w0 + ai];
+                if (cl > w.lstar) { accepted[pl] = 1; wl[pl] = cl; }
+                else if (tcur[pl] < 0.) tmin[pl] = tcur[pl];
+                else tmax[pl] = tcur[pl];
+            }
+            __syncthreads();
+            for (int i = tid; i < nact * D; i += kThreads) {
+                const int ai = i / D, k = i - ai * D, pl = act[ai];
+                if (!accepted[pl]) continue;
+                wu[pl * D + k] = crow[ai * D + k];
+                w.theta[(w0 + pl) * D + k] = a.theta_out[(w0 + ai) * D + k];
+            }
+            __syncthreads();
+            if (tid == 0) {
+                calls += (unsigned long long)nact;
+                int n = 0;
+                for (int ai = 0; ai < nact; ++ai) { const int pl = act[ai]; if (!accepted[pl]) act[n++] = pl; }
+                nact_s[0] = n;
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < nw * D; i += kThreads) w.u[w0 * D + i] = wu[i];
+    for (int i = tid; i < nw; i += kThreads) w.logl[w0 + i] = wl[i];
+    if (tid == 0 && calls) atomicAdd(w.ncalls, calls);
+}
+
 // Scalar-call server (rvll_kernels.h, ServerCtl).  Thread 0 polls the request word in host memory (system-scope
 // acquire; one PCIe read per poll — op and number travel in that one word), the workgroup evaluates the one
 // point exactly as a one-point launch would (same loglike_tile, same bits) into device-local scratch, and
@@ -733,6 +865,29 @@ hipError_t launch_loglike(const LoglikeArgs& a, hipStream_t stream)
     case RVLL_PREC_MIXED: hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_MIXED, false>), grid, block, lds, stream, a); break;
     case RVLL_PREC_FP32:  hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP32, false>), grid, block, lds, stream, a); break;
     default:              hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP64, false>), grid, block, lds, stream, a); break;
+    }
+    return hipGetLastError();
+}
+
+size_t walk_lds_bytes(const LoglikeArgs& a)
+{
+    const size_t base = (loglike_lds_bytes(a) + 15) & ~(size_t)15;
+    return base + sizeof(double) * ((size_t)2 * a.PB * a.D + 4 * a.PB) + sizeof(int) * (2 * a.PB + 2) + 16;
+}
+
+hipError_t launch_slice_walk(const LoglikeArgs& a, const WalkArgs& w, hipStream_t stream)
+{
+    if (w.K <= 0 || w.nsteps <= 0) return hipSuccess;
+    if (!a.cube || !a.theta_out || !a.priors || a.PB * a.D > 4 * kThreads || w.nsteps >= (1 << 18) ||
+        w.max_rounds < 1 || w.max_rounds > 4096 || a.D > 4096)
+        return hipErrorInvalidValue;
+    const size_t lds = walk_lds_bytes(a);
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((w.K + a.PB - 1) / a.PB)), block(kThreads);
+    switch (a.precision) {
+    case RVLL_PREC_MIXED: hipLaunchKernelGGL((slice_walk_kernel<RVLL_PREC_MIXED>), grid, block, lds, stream, a, w); break;
+    case RVLL_PREC_FP32:  hipLaunchKernelGGL((slice_walk_kernel<RVLL_PREC_FP32>), grid, block, lds, stream, a, w); break;
+    default:              hipLaunchKernelGGL((slice_walk_kernel<RVLL_PREC_FP64>), grid, block, lds, stream, a, w); break;
     }
     return hipGetLastError();
 }

@@ -221,6 +221,27 @@ class GpuRVModel:
     def dev_loglike(self, n):
         _abi.check(self._lib.rvll_dev_loglike(self._h, int(n)))
 
+    def slice_walk(self, cube, theta, logl, lstar, chol, wrapped=None, nsteps=10, max_rounds=200, seed=0):
+        """nsteps slice-sampling moves of every walker inside logL > lstar, entirely on the GPU
+        (rvll_slice_walk).  cube/theta/logl are the walkers' start points; returns (cube, theta, logl, ncalls)
+        of the end points.  chol: lower-triangular factor of the live points' covariance in the unit cube."""
+        cube = np.array(self._theta2d(cube), dtype=np.float64, order="C")
+        theta = np.array(self._theta2d(theta), dtype=np.float64, order="C")
+        logl = np.array(logl, dtype=np.float64).reshape(-1)
+        k = cube.shape[0]
+        if theta.shape != cube.shape or logl.shape[0] != k:
+            raise ValueError("cube, theta and logl must describe the same walkers")
+        chol = np.ascontiguousarray(chol, dtype=np.float64)
+        if chol.shape != (self.ndim, self.ndim):
+            raise ValueError("chol must be [ndim, ndim]")
+        wr = None if wrapped is None else np.ascontiguousarray(np.asarray(wrapped, dtype=bool).astype(np.int32))
+        ncalls = C.c_int64(0)
+        _abi.check(self._lib.rvll_slice_walk(
+            self._h, _abi.as_dp(cube), _abi.as_dp(theta), _abi.as_dp(logl), k, float(lstar), _abi.as_dp(chol),
+            _abi.as_ip(wr) if wr is not None else None, int(nsteps), int(max_rounds), int(seed) & (2 ** 64 - 1),
+            C.byref(ncalls)))
+        return cube, theta, logl, int(ncalls.value)
+
     def scalar_server(self, enable=True):
         """Answer scalar log_likelihood(x) calls through a persistent kernel polling pinned host memory (a PCIe
         round trip instead of a launch + synchronisation; same bits).  Any other call on this model stops the

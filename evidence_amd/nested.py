@@ -146,11 +146,14 @@ def _chord(u, d, wrapped):
 def run_nested_slice(prior: Callable, loglike: Callable, ndim: int, nlive: int = 400, kbatch: Optional[int] = None,
                      nsteps: Optional[int] = None, dlogz: float = 0.5, max_iter: int = 10_000_000,
                      max_calls: int = 50_000_000, wrapped=None, seed: int = 0,
-                     prior_loglike: Optional[Callable] = None) -> NestedResult:
+                     prior_loglike: Optional[Callable] = None, walker: Optional[Callable] = None) -> NestedResult:
     """Nested sampling with `kbatch` deaths per iteration and batched hit-and-run slice sampling.
 
     `prior_loglike(cubes) -> (theta, logl)`, if given, replaces the prior + loglike pair inside the loop
     (GpuRVModel.prior_loglike_batch: one upload, two launches, one download per round).
+    `walker(cube, theta, logl, lstar, chol, wrapped, nsteps, max_rounds, seed) -> (cube, theta, logl, ncalls)`,
+    if given, runs all `nsteps` moves of all replacement walkers in ONE call (GpuRVModel.slice_walk: the whole
+    walk — directions, chords, candidates, prior transform, log-L, accept / shrink — stays on the GPU).
 
     Each iteration removes the `kbatch` lowest live points in order (the live count shrinks nlive,
     nlive-1, ... while they die, as in dynamic nested sampling), then draws `kbatch` replacements above
@@ -194,7 +197,10 @@ def run_nested_slice(prior: Callable, loglike: Callable, ndim: int, nlive: int =
         chol = np.linalg.cholesky(cov)
         start = alive[rng.integers(0, len(alive), kbatch)]
         wu, wt, wl = u[start].copy(), theta[start].copy(), logl[start].copy()
-        for _ in range(nsteps):
+        if walker is not None:
+            wu, wt, wl, used = walker(wu, wt, wl, lstar, chol, wrapped, nsteps, 200, int(rng.integers(0, 2 ** 62)))
+            ncall += int(used)
+        for _ in range(0 if walker is not None else nsteps):
             z = rng.standard_normal((kbatch, ndim))
             d = z @ chol.T
             d /= np.linalg.norm(d, axis=1, keepdims=True)

@@ -214,6 +214,22 @@ int rvll_prior_batch(rvll_handle* h, const double* cube, int64_t B, double* thet
 int rvll_prior_loglike_batch(rvll_handle* h, const double* cube, int64_t B,
                              double* theta_out, double* logL, int32_t* flags);
 
+/* ---- sampler proposal step on the device ---------------------------------------------------------------- */
+/* The callers of the path: nested sampling replaces its worst points by new points drawn
+ * from the prior inside logL > lstar.  The reference leaves that to UltraNest's region slice sampler
+ * (evidence/ultranest/__init__.py:159-175: RegionSliceSampler, nsteps moves per new point, circular omega / ml0);
+ * evidence_amd/nested.py does the same with batched callbacks.  This entry point runs the whole walk on the GPU:
+ * K walkers start at cube[K, ndim] (theta / logl hold their transformed parameters and log-L, all above lstar)
+ * and take nsteps hit-and-run slice moves each: direction = chol * normal / norm (chol: [ndim, ndim] row-major
+ * lower-triangular factor of the live points' covariance), chord limited by the unit-cube walls (wrapped[k] != 0:
+ * circular parameter, half a turn), candidate = uniform point of the chord -> prior transform -> log-L, accepted
+ * if logL > lstar, else the chord shrinks towards the current point (at most max_rounds candidates per move).
+ * In/out buffers return the end points; *ncalls = likelihood evaluations spent.  Deterministic for a given
+ * seed.  Needs rvll_set_priors.                                                                              */
+int rvll_slice_walk(rvll_handle* h, double* cube, double* theta, double* logl, int64_t K, double lstar,
+                    const double* chol, const int32_t* wrapped /*[ndim] or NULL*/, int32_t nsteps,
+                    int32_t max_rounds, uint64_t seed, int64_t* ncalls);
+
 /* ---- scalar-callback latency ------------------------------------------------------------------------- */
 /* PolyChord's loglike(theta) is irreducibly scalar (evidence/polychord/__init__.py:166-171): one theta per call.
  * With the server enabled, rvll_loglike_batch(B = 1) is answered by a persistent one-workgroup kernel that polls

@@ -1,0 +1,97 @@
+"""The device-resident slice-sampling walk (rvll_slice_walk, GpuRVModel.slice_walk): invariants of one walk,
+uniformity without a constraint, the analytic Gaussian evidence, and the 51 Peg evidence against the host-driven
+walk of the same sampler."""
+import numpy as np
+import pytest
+
+from evidence_amd import GpuRVModel
+from evidence_amd.callbacks import make_ultranest_callbacks, wrapped_params
+from evidence_amd.nested import run_nested_slice
+from evidence_amd.synthetic import make_workload
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(300)]
+
+
+def _start(m, w, k, seed, quantile=0.5):
+    rng = np.random.default_rng(seed)
+    cube = rng.random((k, m.ndim))
+    theta, logl = m.prior_loglike_batch(cube)
+    lstar = float(np.quantile(logl, quantile))
+    keep = logl > lstar
+    cube, theta, logl = cube[keep], theta[keep], logl[keep]
+    d0 = cube - cube.mean(axis=0)
+    chol = np.linalg.cholesky(d0.T @ d0 / (len(cube) - 1) + 1e-14 * np.eye(m.ndim))
+    return cube, theta, logl, lstar, chol
+
+
+@pytest.mark.parametrize("cfg, k", [(3, 3000), (1, 700), (5, 300)])
+def test_walk_invariants(gpu_required, cfg, k):
+    w = make_workload(cfg)
+    with GpuRVModel(w.fixedpardict, w.table, w.parnames, priordict=w.priordict()) as m:
+        cube, theta, logl, lstar, chol = _start(m, w, k, seed=cfg)
+        wr = wrapped_params(m.parnames)
+        c2, t2, l2, n = m.slice_walk(cube, theta, logl, lstar, chol, wr, nsteps=12, seed=11)
+        th_chk, ll_chk = m.prior_loglike_batch(c2)
+        c3, t3, l3, n3 = m.slice_walk(cube, theta, logl, lstar, chol, wr, nsteps=12, seed=11)
+        c4, _, _, _ = m.slice_walk(cube, theta, logl, lstar, chol, wr, nsteps=12, seed=12)
+        c0, t0, l0, n0 = m.slice_walk(cube, theta, logl, lstar, chol, wr, nsteps=0, seed=11)
+    assert (l2 > lstar).all() and ((c2 >= 0) & (c2 < 1)).all()
+    assert np.array_equal(th_chk, t2) and np.array_equal(ll_chk, l2)          # outputs describe the same points
+    assert n >= 12 * len(cube) and np.mean(np.any(c2 != cube, axis=1)) > 0.99
+    assert np.array_equal(c2, c3) and np.array_equal(l2, l3) and n == n3      # deterministic for a seed
+    assert not np.array_equal(c2, c4)
+    assert np.array_equal(c0, cube) and np.array_equal(l0, logl) and n0 == 0   # nsteps = 0: nothing moves
+
+
+def test_unconstrained_walk_is_uniform_in_the_cube(gpu_required):
+    """lstar = -inf: every first candidate is accepted, so a long walk must forget its start and fill the unit
+    cube uniformly — walls, circular parameters and the chord logic included."""
+    w = make_workload(2)
+    with GpuRVModel(w.fixedpardict, w.table, w.parnames, priordict=w.priordict()) as m:
+        k = 20000
+        cube = np.full((k, m.ndim), 0.31)
+        theta, logl = m.prior_loglike_batch(cube)
+        wr = wrapped_params(m.parnames)
+        c, t, l, n = m.slice_walk(cube, theta, logl, -np.inf, np.eye(m.ndim), wr, nsteps=40, seed=5)
+    assert n == 40 * k
+    assert np.abs(c.mean(axis=0) - 0.5).max() < 0.01
+    assert np.abs(c.var(axis=0) - 1.0 / 12.0).max() < 0.004
+    assert np.abs(np.corrcoef(c.T) - np.eye(m.ndim)).max() < 0.03
+    hist = np.stack([np.histogram(c[:, j], bins=10, range=(0, 1))[0] for j in range(m.ndim)])
+    assert np.abs(hist / k - 0.1).max() < 0.012
+
+
+def test_gaussian_evidence_with_the_walk_on_the_device(gpu_required):
+    """Two free offsets, one unit-variance datum each, no planet: log-L = -(a^2 + b^2)/2 - ln 2pi, so with
+    Uniform(-10, 10) priors ln Z = -ln 400 = -5.9915 (the reference's 2-D Gaussian known answer, shifted by
+    the normalisation: tests/test_polychord.py:139)."""
+    from evidence_amd import priors as P
+    from evidence_amd.data import EpochTable
+    table = EpochTable.from_arrays(["a", "b"], [1.0, 2.0], [0.0, 0.0], [1.0, 1.0], [0, 1])
+    pri = {"a_offset": P.Uniform(-10, 10), "b_offset": P.Uniform(-10, 10)}
+    with GpuRVModel({}, table, list(pri), priordict=pri) as m:
+        prior, loglike = make_ultranest_callbacks(m, vectorized=True)
+        out = [run_nested_slice(prior, loglike, 2, nlive=1000, dlogz=0.01, seed=s, walker=m.slice_walk,
+                                nsteps=10, max_calls=20_000_000) for s in (1, 2, 3)]
+    for r in out:
+        assert abs(r.logz - (-np.log(400.0))) < 4 * r.logzerr + 0.05, (r.logz, r.logzerr)
+    assert abs(np.mean([r.logz for r in out]) + np.log(400.0)) < 0.12
+
+
+def test_51peg_evidence_device_walk_agrees_with_host_walk(gpu_required):
+    from pathlib import Path
+    from evidence_amd.config import read_config
+    cfg = Path(__file__).resolve().parents[1] / "examples" / "51peg" / "config_51peg.py"
+    rundict, datadict, priordict, fixed = read_config(cfg, nplanets=1)
+    with GpuRVModel(fixed, datadict, list(priordict), priordict=priordict) as m:
+        prior, loglike = make_ultranest_callbacks(m, vectorized=True)
+        wrap = wrapped_params(m.parnames)
+        kw = dict(nlive=400, dlogz=0.5, wrapped=wrap, max_calls=8_000_000)
+        host = run_nested_slice(prior, loglike, m.ndim, seed=1, prior_loglike=m.prior_loglike_batch, **kw)
+        dev = [run_nested_slice(prior, loglike, m.ndim, seed=s, walker=m.slice_walk, **kw) for s in (1, 2)]
+    for d in dev:
+        assert abs(d.logz - host.logz) < 5 * np.hypot(d.logzerr, host.logzerr) + 0.5, (d.logz, host.logz)
+        wgt = np.exp(d.logwt)
+        ip, ik = m.parnames.index("planet1_period"), m.parnames.index("planet1_k1")
+        assert abs(np.sum(wgt * d.samples[:, ip]) - 4.2308) < 0.01
+        assert abs(np.sum(wgt * d.samples[:, ik]) - 56.0) < 6.0
