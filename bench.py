@@ -389,6 +389,18 @@ def main():
             model.scalar_server(False)
             out["scalar_call_us"] = {"launch_per_call": lat["launch"], "persistent_kernel": lat["server"]}
             model.dev_upload_theta(theta)
+            # end to end: nested sampling with the proposal walk on the device (never `value`)
+            from evidence_amd.callbacks import make_ultranest_callbacks, wrapped_params
+            from evidence_amd.nested import run_nested_slice
+            vprior, vloglike = make_ultranest_callbacks(model, vectorized=True)
+            t1 = time.perf_counter()
+            ns = run_nested_slice(vprior, vloglike, model.ndim, nlive=32768, kbatch=16384, dlogz=1e-9,
+                                  max_calls=60_000_000, wrapped=wrapped_params(model.parnames), seed=1,
+                                  prior_loglike=model.prior_loglike_batch, walker=model.slice_walk)
+            out["nested_sampling_end_to_end"] = {"likelihood_calls_per_s": ns.ncall / (time.perf_counter() - t1),
+                                                 "calls": int(ns.ncall), "live_points": 32768, "deaths_per_iteration": 16384,
+                                                 "walk": "device (rvll_slice_walk)"}
+            model.dev_upload_theta(theta)
             out["fip_periodogram"] = fip_extra(not args.no_cpu)
         if not args.no_cpu and world == 1:
             cpu, perr, mean_it = cpu_baseline(w, model.layout, theta, gpu_logl, args.cpu_seconds)

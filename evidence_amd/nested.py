@@ -181,14 +181,20 @@ def run_nested_slice(prior: Callable, loglike: Callable, ndim: int, nlive: int =
         order = np.argsort(logl, kind="stable")
         dead = order[:kbatch]
         lstar = logl[dead[-1]]
-        for i, idx in enumerate(dead):                                  # deaths in order, live count nlive - i
-            logx_new = logx - 1.0 / (nlive - i)
-            logw = np.log(np.exp(logx) - np.exp(logx_new)) + logl[idx]
-            logz_new = np.logaddexp(logz, logw)
-            h_old = np.exp(logz - logz_new) * (h + logz) if np.isfinite(logz) else 0.0
-            h = np.exp(logw - logz_new) * logl[idx] + h_old - logz_new
-            logz, logx = logz_new, logx_new
-            dead_theta.append(theta[idx].copy()); dead_logl.append(logl[idx]); dead_logw.append(logw)
+        # the kbatch deaths in order, live count nlive - i while they die — vectorised (this loop used to cost more
+        # than the likelihood calls): X shrinks by exp(-1/(nlive - i)), w_i = (X_{i-1} - X_i) L_i, Z accumulates,
+        # and the information H follows from A = sum_j w_j ln L_j / Z = H + ln Z
+        dl = logl[dead]
+        logx_seq = logx - np.cumsum(1.0 / (nlive - np.arange(kbatch)))
+        logx_prev = np.concatenate([[logx], logx_seq[:-1]])
+        logw = logx_prev + np.log1p(-np.exp(logx_seq - logx_prev)) + dl
+        logz_seq = np.logaddexp.accumulate(np.concatenate([[logz], logw]))[1:]
+        big = max(logz, float(np.max(logw))) if np.isfinite(logz) else float(np.max(logw))
+        a_prev = np.exp(logz - big) * (h + logz) if np.isfinite(logz) else 0.0
+        a_last = np.exp(big - logz_seq[-1]) * (a_prev + float(np.sum(np.exp(logw - big) * dl)))
+        logz, logx = float(logz_seq[-1]), float(logx_seq[-1])
+        h = float(a_last - logz)
+        dead_theta.append(theta[dead].copy()); dead_logl.append(dl.copy()); dead_logw.append(logw)
         it += kbatch
         alive = order[kbatch:]
         # whitening from the surviving live points
@@ -233,8 +239,8 @@ def run_nested_slice(prior: Callable, loglike: Callable, ndim: int, nlive: int =
             break
     logw_live = logx - np.log(nlive) + logl
     logz_final = np.logaddexp(logz, _logaddexp_many(logw_live))
-    all_theta = np.vstack([np.array(dead_theta).reshape(-1, ndim), theta])
-    all_logl = np.concatenate([dead_logl, logl])
-    all_logw = np.concatenate([dead_logw, logw_live]) - logz_final
+    all_theta = np.vstack([a.reshape(-1, ndim) for a in dead_theta] + [theta])
+    all_logl = np.concatenate(dead_logl + [logl])
+    all_logw = np.concatenate(dead_logw + [logw_live]) - logz_final
     return NestedResult(float(logz_final), float(np.sqrt(max(h, 0.0) / nlive)), it, ncall, float(h),
                         all_theta, all_logl, all_logw)

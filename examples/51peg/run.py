@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The reference's 51 Peg example (evidence/examples/51Peg/run.py) on the MI355X engine: read the
 config, build the model, hand the callbacks to a sampler.  Uses UltraNest (vectorized) when it is
-installed, otherwise the in-repo batched driver.  Needs a GPU."""
+installed, otherwise the in-repo batched driver with the proposal walk on the GPU.  Needs a GPU."""
 import sys
 from pathlib import Path
 
@@ -25,6 +25,6 @@ except ImportError:
     from evidence_amd.nested import run_nested_slice
     res = run_nested_slice(prior, loglike, model.ndim, nlive=400, dlogz=0.5, max_calls=20_000_000,
                            wrapped=wrapped_params(model.parnames), seed=int(sys.argv[1]) if len(sys.argv) > 1 else 0,
-                           prior_loglike=model.prior_loglike_batch)
+                           prior_loglike=model.prior_loglike_batch, walker=model.slice_walk)
     print(f"{rundict['target']}: ln Z = {res.logz:.3f} +- {res.logzerr:.3f} "
           f"({res.niter} iterations, {res.ncall} likelihood calls)")

@@ -33,11 +33,29 @@ with GpuRVModel(w.fixedpardict, w.table, w.parnames, priordict=w.priordict()) as
     print("deterministic for a seed:", bool(np.array_equal(c2, c3)) and n == n3)
 
     prior, loglike = make_ultranest_callbacks(m, vectorized=True)
-    for nlive, max_calls in ((400, 2_000_000), (4096, 20_000_000), (16384, 60_000_000)):
+    for nlive, kbatch, max_calls in ((400, 100, 2_000_000), (4096, 1024, 20_000_000), (16384, 4096, 60_000_000),
+                                     (16384, 8192, 60_000_000), (65536, 32768, 200_000_000)):
         for name, kw in (("host walk", {}), ("device walk", {"walker": m.slice_walk})):
+            if name == "host walk" and nlive > 16384:
+                continue
             t0 = time.perf_counter()
-            res = run_nested_slice(prior, loglike, m.ndim, nlive=nlive, dlogz=1e-9, max_calls=max_calls,
+            res = run_nested_slice(prior, loglike, m.ndim, nlive=nlive, kbatch=kbatch, dlogz=1e-9, max_calls=max_calls,
                                    wrapped=wr, seed=1, prior_loglike=m.prior_loglike_batch, **kw)
             dt = time.perf_counter() - t0
-            print(f"nlive={nlive:6d} {name:11s}: {res.ncall} calls in {dt:.2f} s = {res.ncall / dt:.3e} calls/s "
+            print(f"nlive={nlive:6d} kbatch={kbatch:6d} {name:11s}: {res.ncall} calls in {dt:.2f} s = {res.ncall / dt:.3e} calls/s "
                   f"({res.niter} iterations, ln Z so far {res.logz:.2f})", flush=True)
+
+    # where the time goes at 16384 live points: inside the walk call (upload + kernel + download) vs host logic
+    spent = {"walk": 0.0, "calls": 0}
+    def timed_walk(*a):
+        t1 = time.perf_counter()
+        out = m.slice_walk(*a)
+        spent["walk"] += time.perf_counter() - t1
+        spent["calls"] += out[3]
+        return out
+    t0 = time.perf_counter()
+    res = run_nested_slice(prior, loglike, m.ndim, nlive=16384, dlogz=1e-9, max_calls=60_000_000, wrapped=wr, seed=1,
+                           prior_loglike=m.prior_loglike_batch, walker=timed_walk)
+    dt = time.perf_counter() - t0
+    print(f"breakdown nlive=16384: total {dt:.2f} s, inside slice_walk {spent['walk']:.2f} s "
+          f"({spent['calls'] / spent['walk']:.3e} calls/s there), host logic {dt - spent['walk']:.2f} s")
