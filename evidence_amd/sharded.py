@@ -134,6 +134,42 @@ class ShardedPriorLogLike:
         return np.ascontiguousarray(theta_all[keep]), np.ascontiguousarray(logl_all[keep])
 
 
+class ShardedWalker:
+    """The sampler's proposal walk (GpuRVModel.slice_walk) sharded over ranks: every rank runs the same sampler
+    state (same seed), walks its contiguous share of the replacement walkers on its GPU, and one all-gather
+    returns every walker's end point (cube, theta, log-L) and the call count to every rank.  Drop-in for the
+    `walker=` argument of nested.run_nested_slice.  Each rank derives its own seed from the common one (walker
+    indices restart at 0 in every shard), so a run is reproducible for a given seed AND rank count."""
+
+    def __init__(self, rank: int, world: int, walk: Callable):
+        self.rank, self.world, self.walk = rank, world, walk
+
+    def __call__(self, cube, theta, logl, lstar, chol, wrapped, nsteps, max_rounds, seed):
+        import torch
+        import torch.distributed as dist
+        cube = np.ascontiguousarray(cube, dtype=np.float64)
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        logl = np.ascontiguousarray(logl, dtype=np.float64)
+        n, ndim = cube.shape
+        lo, hi = partition(n, self.world)[self.rank]
+        pad = padded_count(n, self.world)
+        mine = np.zeros((pad, 2 * ndim + 2))
+        if hi > lo:
+            # a different seed per rank keeps the shards' random streams apart (walker indices restart at 0)
+            c, t, l, used = self.walk(cube[lo:hi], theta[lo:hi], logl[lo:hi], lstar, chol, wrapped, nsteps,
+                                      max_rounds, (int(seed) + 0x9E3779B97F4A7C15 * (self.rank + 1)) % (2 ** 63))
+            mine[: hi - lo, :ndim], mine[: hi - lo, ndim:2 * ndim], mine[: hi - lo, 2 * ndim] = c, t, l
+            mine[0, 2 * ndim + 1] = used
+        parts = [torch.empty((pad, 2 * ndim + 2), dtype=torch.float64) for _ in range(self.world)]
+        dist.all_gather(parts, torch.from_numpy(mine))
+        both = torch.stack(parts).numpy()
+        keep = [both[r, : h - l] for r, (l, h) in enumerate(partition(n, self.world))]
+        out = np.concatenate(keep) if keep else np.empty((0, 2 * ndim + 2))
+        used_total = int(round(float(both[:, 0, 2 * ndim + 1].sum()))) if pad else 0
+        return (np.ascontiguousarray(out[:, :ndim]), np.ascontiguousarray(out[:, ndim:2 * ndim]),
+                np.ascontiguousarray(out[:, 2 * ndim]), used_total)
+
+
 class MultiDeviceLogLike:
     """One process, several GPUs: the same contiguous live-point shards, one GpuRVModel (handle) per device,
     one host thread per device (the ctypes calls release the GIL, so uploads, kernels and downloads of the

@@ -108,3 +108,49 @@ def test_sharded_prior_loglike_returns_theta_and_logl_everywhere(world, n):
     for rank, th, ll, calls in results:
         assert np.array_equal(th, theta) and np.array_equal(ll, logl)
         assert calls == [padded_count(n, world)]                 # its own shard, padded to the common count
+
+
+def _fake_walk(cube, theta, logl, lstar, chol, wrapped, nsteps, max_rounds, seed):
+    """A deterministic stand-in for GpuRVModel.slice_walk (the GPU walk is tested in tests/test_gpu_walk.py)."""
+    c = (cube * 0.5 + 0.25) % 1.0
+    return c, 10.0 * c - 3.0, logl + 1.0, 3 * len(cube)
+
+
+def _walk_worker(rank, world, port, n, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from evidence_amd.sharded import ShardedWalker
+        rng = np.random.default_rng(3)
+        cube, logl = rng.random((n, 4)), rng.normal(size=n)
+        calls = []
+        def walk(*a):
+            calls.append(len(a[0]))
+            return _fake_walk(*a)
+        out = ShardedWalker(rank, world, walk)(cube, 10.0 * cube - 3.0, logl, -1.0, np.eye(4), None, 5, 200, 17)
+        q.put((rank, out, calls))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n", [(2, 40), (3, 31), (2, 1)])
+def test_sharded_walker_gathers_every_walkers_end_point(world, n):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_walk_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(3)
+    cube, logl = rng.random((n, 4)), rng.normal(size=n)
+    c, t, l, used = _fake_walk(cube, None, logl, 0, 0, 0, 0, 0, 0)
+    for rank, (gc, gt, gl, gused), calls in results:
+        assert np.array_equal(gc, c) and np.array_equal(gt, t) and np.array_equal(gl, l) and gused == 3 * n
+        lo, hi = partition(n, world)[rank]
+        assert calls == ([hi - lo] if hi > lo else [])
