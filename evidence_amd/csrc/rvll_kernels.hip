@@ -474,9 +474,12 @@ void loglike_kernel(const LoglikeArgs a)                                // form 
 // run_nested_slice, which follows the reference's UltraNest wrapper: region slice sampling, nsteps moves per new
 // point, circular omega / ml0 — evidence/ultranest/__init__.py:159-175).  Everything a move needs stays on the
 // chip: counter-based random numbers, directions, chords, candidates (written to the workgroup's scratch rows),
-// prior transform + log-L of the active candidates through the same loglike_tile as every other path, accept /
-// shrink.  Loops are bounded by nsteps * max_rounds; all waves run the same trip counts (the active count is
-// shared through LDS).
+// prior transform + log-L of the candidates through the same loglike_tile as every other path, accept / shrink.
+// The walkers of a workgroup are NOT in lock step: every iteration evaluates one candidate for every walker that
+// still has moves left, and a walker whose candidate was accepted draws its next direction in the following
+// iteration — so the tile stays full until the walkers run out of moves (their totals over nsteps moves are
+// close), instead of idling behind the slowest walker of every move.  Trip counts are bounded by
+// nsteps * max_rounds and shared through LDS, so all waves loop alike.
 template <int PREC>
 __global__ __launch_bounds__(kThreads, 2) __attribute__((flatten))      // 256 VGPRs: prior routines + tile in one loop nest
 void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
@@ -493,107 +496,116 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
     double* tmax = tmin + PB;
     double* tcur = tmax + PB;
     double* wl   = tcur + PB;
-    int* act     = reinterpret_cast<int*>(wl + PB);         // [PB] active walkers (local index), compacted
-    int* accepted = act + PB;                               // [PB]
-    int* nact_s  = accepted + PB;                           // [1]
+    int* act     = reinterpret_cast<int*>(wl + PB);         // [PB] walkers with moves left (local index), compacted
+    int* state   = act + PB;                                // [PB] 0: needs a new direction, 1: in a move, 2: accepted just now
+    int* step_of = state + PB;                              // [PB] moves completed
+    int* round_of = step_of + PB;                           // [PB] candidates tried in the current move
+    int* nact_s  = round_of + PB;                           // [1]
     const double one_below = 0.99999999999999988898;        // nextafter(1, 0)
 
     for (int i = tid; i < nw * D; i += kThreads) wu[i] = w.u[w0 * D + i];
-    for (int i = tid; i < nw; i += kThreads) wl[i] = w.logl[w0 + i];
+    for (int i = tid; i < nw; i += kThreads) { wl[i] = w.logl[w0 + i]; state[i] = 0; step_of[i] = 0; round_of[i] = 0; act[i] = i; }
+    if (tid == 0) nact_s[0] = nw;
     unsigned long long calls = 0;                           // thread 0 only
     __syncthreads();
 
-    for (int step = 0; step < w.nsteps; ++step) {
-        // standard normals (Box-Muller on two counter-based uniforms)
-        for (int i = tid; i < nw * D; i += kThreads) {
-            const int pl = i / D, k = i - pl * D;
-            const unsigned long long ctr = ((unsigned long long)(w0 + pl) << 32) | ((unsigned long long)step << 14) | (unsigned)(2 * k);
+    const long long max_iters = (long long)w.nsteps * w.max_rounds;
+    for (long long iter = 0; iter < max_iters; ++iter) {
+        const int nact = nact_s[0];
+        if (nact == 0) break;
+        // walkers starting a move: standard normals (Box-Muller on two counter-based uniforms) ...
+        for (int i = tid; i < nact * D; i += kThreads) {
+            const int pl = act[i / D], k = i % D;
+            if (state[pl] != 0) continue;
+            const unsigned long long ctr = ((unsigned long long)(w0 + pl) << 32) | ((unsigned long long)step_of[pl] << 14) | (unsigned)(2 * k);
             const double u1 = uniform01(w.seed, ctr), u2 = uniform01(w.seed, ctr + 1);
             double sn, cs;
             sincos_f64(kTwoPi * u2, sn, cs);
-            dir[i] = sqrt(-2. * log(1. - u1)) * cs;
+            dir[pl * D + k] = sqrt(-2. * log(1. - u1)) * cs;
         }
         __syncthreads();
-        // direction = chol * z (lower triangular), into tcur-free scratch: reuse the candidate rows in registers
-        double mine[4];                                     // up to 4 elements per thread (PB * D <= 1024)
+        // ... direction = chol * z (lower triangular; held in registers until every z has been read) ...
+        double mine[4];                                     // PB * D <= 4 * kThreads
         int cnt = 0;
-        for (int i = tid; i < nw * D; i += kThreads) {
-            const int pl = i / D, k = i - pl * D;
+        for (int i = tid; i < nact * D; i += kThreads, ++cnt) {
+            const int pl = act[i / D], k = i % D;
+            if (state[pl] != 0) continue;
             double acc = 0.;
             for (int j = 0; j <= k; ++j) acc += w.chol[k * D + j] * dir[pl * D + j];
-            mine[cnt++ & 3] = acc;
+            mine[cnt & 3] = acc;
         }
         __syncthreads();
         cnt = 0;
-        for (int i = tid; i < nw * D; i += kThreads) dir[i] = mine[cnt++ & 3];
-        __syncthreads();
-        // one thread per walker: normalise, chord, activate
-        for (int pl = tid; pl < nw; pl += kThreads) {
-            double n2 = 0.;
-            for (int k = 0; k < D; ++k) n2 += dir[pl * D + k] * dir[pl * D + k];
-            const double inv = 1. / sqrt(n2);
-            double lo = -INFINITY, hi = INFINITY;
-            for (int k = 0; k < D; ++k) {
-                const double d = dir[pl * D + k] * inv, u = wu[pl * D + k];
-                dir[pl * D + k] = d;
-                if (d == 0.) continue;
-                if (w.wrapped[k]) {
-                    const double half = 0.5 / fabs(d);
-                    lo = fmax(lo, -half); hi = fmin(hi, half);
-                } else {
-                    const double t0 = (0. - u) / d, t1 = (1. - u) / d;
-                    lo = fmax(lo, fmin(t0, t1)); hi = fmin(hi, fmax(t0, t1));
-                }
-            }
-            tmin[pl] = lo; tmax[pl] = hi;
-            act[pl] = pl;
+        for (int i = tid; i < nact * D; i += kThreads, ++cnt) {
+            const int pl = act[i / D], k = i % D;
+            if (state[pl] == 0) dir[pl * D + k] = mine[cnt & 3];
         }
-        if (tid == 0) nact_s[0] = nw;
         __syncthreads();
-
-        for (int round = 0; round < w.max_rounds; ++round) {
-            const int nact = nact_s[0];
-            if (nact == 0) break;
-            for (int ai = tid; ai < nact; ai += kThreads) {
+        // ... normalise, chord (one thread per walker); then the candidate position along the chord
+        for (int ai = tid; ai < nact; ai += kThreads) {
+            const int pl = act[ai];
+            if (state[pl] == 0) {
+                double n2 = 0.;
+                for (int k = 0; k < D; ++k) n2 += dir[pl * D + k] * dir[pl * D + k];
+                const double inv = 1. / sqrt(n2);
+                double lo = -INFINITY, hi = INFINITY;
+                for (int k = 0; k < D; ++k) {
+                    const double d = dir[pl * D + k] * inv, u = wu[pl * D + k];
+                    dir[pl * D + k] = d;
+                    if (d == 0.) continue;
+                    if (w.wrapped[k]) {
+                        const double half = 0.5 / fabs(d);
+                        lo = fmax(lo, -half); hi = fmin(hi, half);
+                    } else {
+                        const double t0 = (0. - u) / d, t1 = (1. - u) / d;
+                        lo = fmax(lo, fmin(t0, t1)); hi = fmin(hi, fmax(t0, t1));
+                    }
+                }
+                tmin[pl] = lo; tmax[pl] = hi;
+                round_of[pl] = 0;
+                state[pl] = 1;
+            }
+            const unsigned long long ctr = ((unsigned long long)(w0 + pl) << 32) | ((unsigned long long)step_of[pl] << 14) |
+                                           (unsigned)(8192 + round_of[pl]);
+            tcur[pl] = tmin[pl] + (tmax[pl] - tmin[pl]) * uniform01(w.seed, ctr);
+        }
+        __syncthreads();
+        double* crow = const_cast<double*>(a.cube) + w0 * D;           // this workgroup's scratch rows
+        for (int i = tid; i < nact * D; i += kThreads) {
+            const int ai = i / D, k = i - ai * D, pl = act[ai];
+            double c = wu[pl * D + k] + tcur[pl] * dir[pl * D + k];
+            if (w.wrapped[k]) c -= floor(c);
+            crow[ai * D + k] = fmin(fmax(c, 0.), one_below);
+        }
+        __syncthreads();
+        loglike_tile<PREC, true>(a, smem, w0, nact);                   // prior transform + log-L of the candidates
+        __syncthreads();
+        for (int ai = tid; ai < nact; ai += kThreads) {
+            const int pl = act[ai];
+            const double cl = a.logL[w0 + ai];
+            if (cl > w.lstar) { state[pl] = 2; wl[pl] = cl; }
+            else {
+                if (tcur[pl] < 0.) tmin[pl] = tcur[pl]; else tmax[pl] = tcur[pl];
+                if (++round_of[pl] >= w.max_rounds) { state[pl] = 0; step_of[pl] += 1; }   // give the move up, stay put
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < nact * D; i += kThreads) {
+            const int ai = i / D, k = i - ai * D, pl = act[ai];
+            if (state[pl] != 2) continue;
+            wu[pl * D + k] = crow[ai * D + k];
+            w.theta[(w0 + pl) * D + k] = a.theta_out[(w0 + ai) * D + k];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            calls += (unsigned long long)nact;
+            int n = 0;
+            for (int ai = 0; ai < nact; ++ai) {
                 const int pl = act[ai];
-                const unsigned long long ctr = ((unsigned long long)(w0 + pl) << 32) | ((unsigned long long)step << 14) |
-                                               (unsigned)(8192 + round);
-                tcur[pl] = tmin[pl] + (tmax[pl] - tmin[pl]) * uniform01(w.seed, ctr);
-                accepted[pl] = 0;
+                if (state[pl] == 2) { state[pl] = 0; step_of[pl] += 1; }
+                if (step_of[pl] < w.nsteps) act[n++] = pl;
             }
-            __syncthreads();
-            double* crow = const_cast<double*>(a.cube) + w0 * D;       // this workgroup's scratch rows
-            for (int i = tid; i < nact * D; i += kThreads) {
-                const int ai = i / D, k = i - ai * D, pl = act[ai];
-                double c = wu[pl * D + k] + tcur[pl] * dir[pl * D + k];
-                if (w.wrapped[k]) c -= floor(c);
-                crow[ai * D + k] = fmin(fmax(c, 0.), one_below);
-            }
-            __syncthreads();
-            loglike_tile<PREC, true>(a, smem, w0, nact);               // prior transform + log-L of the candidates
-            __syncthreads();
-            for (int ai = tid; ai < nact; ai += kThreads) {
-                const int pl = act[ai];
-                const double cl = a.logL[w0 + ai];
-                if (cl > w.lstar) { accepted[pl] = 1; wl[pl] = cl; }
-                else if (tcur[pl] < 0.) tmin[pl] = tcur[pl];
-                else tmax[pl] = tcur[pl];
-            }
-            __syncthreads();
-            for (int i = tid; i < nact * D; i += kThreads) {
-                const int ai = i / D, k = i - ai * D, pl = act[ai];
-                if (!accepted[pl]) continue;
-                wu[pl * D + k] = crow[ai * D + k];
-                w.theta[(w0 + pl) * D + k] = a.theta_out[(w0 + ai) * D + k];
-            }
-            __syncthreads();
-            if (tid == 0) {
-                calls += (unsigned long long)nact;
-                int n = 0;
-                for (int ai = 0; ai < nact; ++ai) { const int pl = act[ai]; if (!accepted[pl]) act[n++] = pl; }
-                nact_s[0] = n;
-            }
-            __syncthreads();
+            nact_s[0] = n;
         }
         __syncthreads();
     }
@@ -872,7 +884,7 @@ hipError_t launch_loglike(const LoglikeArgs& a, hipStream_t stream)
 size_t walk_lds_bytes(const LoglikeArgs& a)
 {
     const size_t base = (loglike_lds_bytes(a) + 15) & ~(size_t)15;
-    return base + sizeof(double) * ((size_t)2 * a.PB * a.D + 4 * a.PB) + sizeof(int) * (2 * a.PB + 2) + 16;
+    return base + sizeof(double) * ((size_t)2 * a.PB * a.D + 4 * a.PB) + sizeof(int) * (4 * a.PB + 2) + 16;
 }
 
 hipError_t launch_slice_walk(const LoglikeArgs& a, const WalkArgs& w, hipStream_t stream)
