@@ -43,6 +43,21 @@ def test_walk_invariants(gpu_required, cfg, k):
     assert np.array_equal(c0, cube) and np.array_equal(l0, logl) and n0 == 0   # nsteps = 0: nothing moves
 
 
+def test_walk_gives_up_a_move_after_max_rounds_and_accepts_no_wrapping(gpu_required):
+    """A tight constraint with max_rounds = 1: most candidates are rejected and the move is given up — the walker
+    stays where it was, still above lstar; ncalls counts exactly the one candidate per walker.  wrapped=None works."""
+    w = make_workload(3)
+    with GpuRVModel(w.fixedpardict, w.table, w.parnames, priordict=w.priordict()) as m:
+        cube, theta, logl, lstar, chol = _start(m, w, 4000, seed=9, quantile=0.97)
+        c2, t2, l2, n = m.slice_walk(cube, theta, logl, lstar, chol, None, nsteps=1, max_rounds=1, seed=3)
+        th_chk, ll_chk = m.prior_loglike_batch(c2)
+    assert n == len(cube)
+    assert (l2 > lstar).all() and np.array_equal(ll_chk, l2) and np.array_equal(th_chk, t2)
+    stayed = np.all(c2 == cube, axis=1)
+    assert 0.05 < stayed.mean() < 0.95                       # the one candidate was rejected for these
+    assert np.array_equal(l2[stayed], logl[stayed]) and np.array_equal(t2[stayed], theta[stayed])
+
+
 def test_unconstrained_walk_is_uniform_in_the_cube(gpu_required):
     """lstar = -inf: every first candidate is accepted, so a long walk must forget its start and fill the unit
     cube uniformly — walls, circular parameters and the chord logic included."""
