@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Soak of the device-resident walk and the scalar-call server: for --seconds, random walks on changing configs
+whose end points are re-evaluated from scratch (theta / log-L must match bit for bit, every end point above the
+threshold), interleaved with scalar calls through the persistent kernel.  Run on the GPU box."""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from evidence_amd import GpuRVModel
+from evidence_amd.callbacks import wrapped_params
+from evidence_amd.synthetic import make_workload
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seconds", type=float, default=60.0)
+args = ap.parse_args()
+rng = np.random.default_rng(123)
+t_end = time.time() + args.seconds
+walks = calls = scalars = 0
+models = {}
+for cfg in (1, 2, 3, 5):
+    w = make_workload(cfg)
+    models[cfg] = (w, GpuRVModel(w.fixedpardict, w.table, w.parnames, priordict=w.priordict()))
+last = time.time()
+while time.time() < t_end:
+    cfg = int(rng.choice([1, 2, 3, 3, 3, 5]))
+    w, m = models[cfg]
+    k = int(rng.integers(1, 6000 if cfg != 5 else 600))
+    cube = rng.random((2 * k, m.ndim))
+    theta, logl = m.prior_loglike_batch(cube)
+    lstar = float(np.quantile(logl, rng.uniform(0.3, 0.98)))
+    keep = logl > lstar
+    if keep.sum() < 2:
+        continue
+    cube, theta, logl = cube[keep], theta[keep], logl[keep]
+    d0 = cube - cube.mean(axis=0)
+    chol = np.linalg.cholesky(d0.T @ d0 / max(1, len(cube) - 1) + 1e-10 * np.eye(m.ndim))
+    c2, t2, l2, n = m.slice_walk(cube, theta, logl, lstar, chol, wrapped_params(m.parnames), nsteps=int(rng.integers(1, 30)),
+                                 max_rounds=int(rng.choice([1, 3, 200])), seed=int(rng.integers(0, 2 ** 62)))
+    th_chk, ll_chk = m.prior_loglike_batch(c2)
+    assert (l2 > lstar).all(), "end point below the threshold"
+    assert np.array_equal(th_chk, t2) and np.array_equal(ll_chk, l2), "end points do not describe the returned cubes"
+    walks += 1; calls += n
+    m.scalar_server(True)
+    for x, want in zip(t2[:20], l2[:20]):
+        assert m.log_likelihood(x) == want, "scalar server disagrees"
+        scalars += 1
+    if rng.random() < 0.5:
+        m.scalar_server(False)
+    if time.time() - last > 20:
+        last = time.time()
+        print(f"... {walks} walks, {calls} likelihood calls, {scalars} scalar calls", flush=True)
+for w, m in models.values():
+    m.close()
+print(f"soak ok: {walks} walks, {calls} likelihood calls inside walks, {scalars} scalar-server calls, all consistent")
