@@ -93,6 +93,25 @@ def test_gaussian_evidence_with_the_walk_on_the_device(gpu_required):
     assert abs(np.mean([r.logz for r in out]) + np.log(400.0)) < 0.12
 
 
+def test_device_walk_is_unbiased_on_a_4d_gaussian(gpu_required):
+    """Many seeds on a likelihood with an analytic evidence (four free offsets, one unit-variance datum each:
+    ln Z = -4 ln 20): the mean over seeds must sit on the truth within its standard error — a biased walk
+    (wrong chord, wrong acceptance, correlated random numbers) shows up here, a single run would hide it."""
+    from evidence_amd import priors as P
+    from evidence_amd.data import EpochTable
+    names = ["a", "b", "c", "d"]
+    table = EpochTable.from_arrays(names, [1.0, 2.0, 3.0, 4.0], [0.3, -0.2, 0.1, 0.0], [1.0] * 4, [0, 1, 2, 3])
+    pri = {f"{n}_offset": P.Uniform(-10, 10) for n in names}
+    truth = -4 * np.log(20.0)
+    with GpuRVModel({}, table, list(pri), priordict=pri) as m:
+        prior, loglike = make_ultranest_callbacks(m, vectorized=True)
+        z = np.array([run_nested_slice(prior, loglike, 4, nlive=1000, kbatch=500, dlogz=0.01, nsteps=12, seed=s,
+                                       walker=m.slice_walk, max_calls=50_000_000).logz for s in range(1, 25)])
+    se = z.std(ddof=1) / np.sqrt(len(z))
+    assert abs(z.mean() - truth) < 4 * se + 0.01, (z.mean() - truth, se)
+    assert z.std() < 0.15                                   # ~ sqrt(H / nlive) with H ~ 6
+
+
 def test_51peg_evidence_device_walk_agrees_with_host_walk(gpu_required):
     from pathlib import Path
     from evidence_amd.config import read_config
