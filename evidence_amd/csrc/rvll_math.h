@@ -54,8 +54,8 @@ RVLL_HD void sincos_kernel(double r, double& sr, double& cr)
         "v_fma_f64 %0, %3, %0, %4\n\t"
         "v_fma_f64 %1, %2, %1, 1.0"
         : "=&v"(sr), "=&v"(cr), "=&v"(z), "=&v"(t)
-        : "v"(r), "v"(S1), "v"(S2), "v"(S3), "v"(S4), "v"(S5), "v"(S6),
-          "v"(C1), "v"(C2), "v"(C3), "v"(C4), "v"(C5), "v"(C6));
+        : "v"(r), "s"(S1), "s"(S2), "s"(S3), "s"(S4), "s"(S5), "v"(S6),
+          "s"(C1), "s"(C2), "s"(C3), "s"(C4), "s"(C5), "v"(C6));      // one scalar operand per VALU instruction
 #else
     const double z = r * r;
     double ps = __builtin_fma(z, S6, S5);
