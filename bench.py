@@ -208,6 +208,87 @@ def fip_extra(with_cpu):
     return res
 
 
+def run_extras(out, model, w, theta, B, with_cpu):
+    """Extras of the N = 1 line (never `value`).  Each one is guarded: an extra that fails is reported under
+    `extras_failed` and can never suppress the headline line."""
+    def guarded(name, fn):
+        try:
+            fn()
+        except Exception as exc:                                  # noqa: BLE001 — report, do not lose the line
+            out.setdefault("extras_failed", {})[name] = f"{type(exc).__name__}: {exc}"
+        finally:
+            try:
+                model.scalar_server(False)
+                if model.dev_flip_lane() != 0:
+                    model.dev_flip_lane()
+                model.dev_upload_theta(theta)
+            except Exception:                                     # noqa: BLE001
+                pass
+
+    def host_roundtrip():                 # PCIe-inclusive: host theta in, host log-L out
+        model.log_likelihood_batch(theta)
+        t1 = time.perf_counter()
+        for _ in range(10):
+            model.log_likelihood_batch(theta)
+        out["host_roundtrip_evals_per_s"] = 10 * B / (time.perf_counter() - t1)
+
+    def two_lanes():                      # two launches in flight on alternating pipeline lanes (how the N > 1 step
+        for _ in range(100):              # overlaps its all-gather): independent batches hide each other's ramp and tail
+            model.dev_loglike(B); model.dev_flip_lane()
+        model.dev_sync()
+        t1 = time.perf_counter()
+        for _ in range(1000):
+            model.dev_loglike(B); model.dev_flip_lane()
+        model.dev_sync()
+        out["two_lane_pipelined_evals_per_s"] = 1000 * B / (time.perf_counter() - t1)
+
+    def prior_plus_loglike():             # cube -> theta -> log-L all on the device: two launches, and one
+        model.set_priors(w.priordict())
+        model.dev_fill_cube(B, seed=99)
+        for key, step in (("prior_plus_loglike_evals_per_s", lambda: (model.dev_prior(B), model.dev_loglike(B))),
+                          ("prior_plus_loglike_one_launch_evals_per_s", lambda: model.dev_prior_loglike(B))):
+            for _ in range(5):
+                step()
+            model.dev_sync()
+            t1 = time.perf_counter()
+            for _ in range(50):
+                step()
+            model.dev_sync()
+            out[key] = 50 * B / (time.perf_counter() - t1)
+
+    def scalar_calls():                   # PolyChord's form, one theta per call: launch + sync vs the persistent kernel
+        x0, lat = theta[0], {}
+        for mode in ("launch", "server"):
+            model.scalar_server(mode == "server")
+            for _ in range(50):
+                model.log_likelihood(x0)
+            t1 = time.perf_counter()
+            for _ in range(1000):
+                model.log_likelihood(x0)
+            lat[mode] = (time.perf_counter() - t1) / 1000 * 1e6
+        out["scalar_call_us"] = {"launch_per_call": lat["launch"], "persistent_kernel": lat["server"]}
+
+    def nested_sampling():                # end to end with the proposal walk on the device (SURVEY §8 f1)
+        from evidence_amd.callbacks import make_ultranest_callbacks, wrapped_params
+        from evidence_amd.nested import run_nested_slice
+        model.set_priors(w.priordict())
+        vprior, vloglike = make_ultranest_callbacks(model, vectorized=True)
+        t1 = time.perf_counter()
+        ns = run_nested_slice(vprior, vloglike, model.ndim, nlive=32768, kbatch=16384, dlogz=1e-9,
+                              max_calls=60_000_000, wrapped=wrapped_params(model.parnames), seed=1,
+                              prior_loglike=model.prior_loglike_batch, walker=model.slice_walk)
+        out["nested_sampling_end_to_end"] = {"likelihood_calls_per_s": ns.ncall / (time.perf_counter() - t1),
+                                             "calls": int(ns.ncall), "live_points": 32768, "deaths_per_iteration": 16384,
+                                             "walk": "device (rvll_slice_walk)"}
+
+    def fip():
+        out["fip_periodogram"] = fip_extra(with_cpu)
+
+    for name, fn in (("host_roundtrip", host_roundtrip), ("two_lanes", two_lanes), ("prior_plus_loglike", prior_plus_loglike),
+                     ("scalar_calls", scalar_calls), ("nested_sampling", nested_sampling), ("fip", fip)):
+        guarded(name, fn)
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -338,70 +419,7 @@ def main():
                          "note": "fused kernel is fp64-VALU bound, not HBM bound (DESIGN.md); see valu_fp64"},
         }
         if world == 1 and not args.no_extras:
-            # extras (never `value`): PCIe-inclusive host round trip, and cube -> theta -> log-L all on device
-            model.log_likelihood_batch(theta)
-            t1 = time.perf_counter()
-            for _ in range(10):
-                model.log_likelihood_batch(theta)
-            out["host_roundtrip_evals_per_s"] = 10 * B / (time.perf_counter() - t1)
-            # two launches in flight on alternating pipeline lanes (how the N > 1 step overlaps its all-gather):
-            # independent batches hide each other's ramp-up and tail
-            for _ in range(100):
-                model.dev_loglike(B); model.dev_flip_lane()
-            model.dev_sync()
-            t1 = time.perf_counter()
-            for _ in range(1000):
-                model.dev_loglike(B); model.dev_flip_lane()
-            model.dev_sync()
-            out["two_lane_pipelined_evals_per_s"] = 1000 * B / (time.perf_counter() - t1)
-            if model.dev_flip_lane() != 0:
-                model.dev_flip_lane()
-            model.set_priors(w.priordict())
-            model.dev_fill_cube(B, seed=99)
-            for _ in range(5):
-                model.dev_prior(B); model.dev_loglike(B)
-            model.dev_sync()
-            t1 = time.perf_counter()
-            for _ in range(50):
-                model.dev_prior(B); model.dev_loglike(B)
-            model.dev_sync()
-            out["prior_plus_loglike_evals_per_s"] = 50 * B / (time.perf_counter() - t1)
-            for _ in range(5):
-                model.dev_prior_loglike(B)
-            model.dev_sync()
-            t1 = time.perf_counter()
-            for _ in range(50):
-                model.dev_prior_loglike(B)
-            model.dev_sync()
-            out["prior_plus_loglike_one_launch_evals_per_s"] = 50 * B / (time.perf_counter() - t1)
-            model.dev_upload_theta(theta)
-            # scalar callback latency (PolyChord's form: one theta per call): launch + sync vs the persistent kernel
-            x0 = theta[0]
-            lat = {}
-            for mode in ("launch", "server"):
-                model.scalar_server(mode == "server")
-                for _ in range(50):
-                    model.log_likelihood(x0)
-                t1 = time.perf_counter()
-                for _ in range(1000):
-                    model.log_likelihood(x0)
-                lat[mode] = (time.perf_counter() - t1) / 1000 * 1e6
-            model.scalar_server(False)
-            out["scalar_call_us"] = {"launch_per_call": lat["launch"], "persistent_kernel": lat["server"]}
-            model.dev_upload_theta(theta)
-            # end to end: nested sampling with the proposal walk on the device (never `value`)
-            from evidence_amd.callbacks import make_ultranest_callbacks, wrapped_params
-            from evidence_amd.nested import run_nested_slice
-            vprior, vloglike = make_ultranest_callbacks(model, vectorized=True)
-            t1 = time.perf_counter()
-            ns = run_nested_slice(vprior, vloglike, model.ndim, nlive=32768, kbatch=16384, dlogz=1e-9,
-                                  max_calls=60_000_000, wrapped=wrapped_params(model.parnames), seed=1,
-                                  prior_loglike=model.prior_loglike_batch, walker=model.slice_walk)
-            out["nested_sampling_end_to_end"] = {"likelihood_calls_per_s": ns.ncall / (time.perf_counter() - t1),
-                                                 "calls": int(ns.ncall), "live_points": 32768, "deaths_per_iteration": 16384,
-                                                 "walk": "device (rvll_slice_walk)"}
-            model.dev_upload_theta(theta)
-            out["fip_periodogram"] = fip_extra(not args.no_cpu)
+            run_extras(out, model, w, theta, B, not args.no_cpu)
         if not args.no_cpu and world == 1:
             cpu, perr, mean_it = cpu_baseline(w, model.layout, theta, gpu_logl, args.cpu_seconds)
             out["cpu_baseline"] = cpu
