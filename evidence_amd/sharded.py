@@ -209,6 +209,22 @@ class MultiDeviceLogLike:
         res = [f.result() for f in futures if f is not None]
         return np.concatenate([r[0] for r in res]), np.concatenate([r[1] for r in res])
 
+    def slice_walk(self, cube, theta, logl, lstar, chol, wrapped=None, nsteps=10, max_rounds=200, seed=0):
+        """The proposal walk (GpuRVModel.slice_walk) with the walkers sharded over the devices; drop-in for the
+        `walker=` argument of nested.run_nested_slice.  Each device gets its own seed derived from `seed`."""
+        cube = np.ascontiguousarray(cube, dtype=np.float64)
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        logl = np.ascontiguousarray(logl, dtype=np.float64)
+        bounds = partition(cube.shape[0], len(self.models))
+        futures = [self._pool.submit(m.slice_walk, cube[lo:hi], theta[lo:hi], logl[lo:hi], lstar, chol, wrapped, nsteps,
+                                     max_rounds, (int(seed) + 0x9E3779B97F4A7C15 * (i + 1)) % (2 ** 63)) if hi > lo else None
+                   for i, (m, (lo, hi)) in enumerate(zip(self.models, bounds))]
+        res = [f.result() for f in futures if f is not None]
+        if not res:
+            return cube, theta, logl, 0
+        return (np.concatenate([r[0] for r in res]), np.concatenate([r[1] for r in res]),
+                np.concatenate([r[2] for r in res]), int(sum(r[3] for r in res)))
+
     def close(self):
         self._pool.shutdown(wait=True)
         for m in self.models:

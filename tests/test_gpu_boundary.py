@@ -175,6 +175,24 @@ def test_single_process_multi_handle_sharding(gpu_required):
         assert np.array_equal(t1, t2) and np.array_equal(l1, l2)
 
 
+def test_single_process_multi_handle_walk(gpu_required):
+    """MultiDeviceLogLike.slice_walk: walkers sharded over two handles (one per GPU on a node); every end point
+    is above the threshold and consistent with a fresh evaluation, whatever handle walked it."""
+    from evidence_amd.sharded import MultiDeviceLogLike
+    w = make_workload(3)
+    with MultiDeviceLogLike.create(w.fixedpardict, w.table, w.parnames, devices=[0, 0], priordict=w.priordict()) as md:
+        cube = np.random.default_rng(2).random((3001, len(w.parnames)))
+        theta, logl = md.prior_loglike_batch(cube)
+        lstar = float(np.median(logl))
+        keep = logl > lstar
+        cube, theta, logl = cube[keep], theta[keep], logl[keep]
+        c2, t2, l2, n = md.slice_walk(cube, theta, logl, lstar, 0.1 * np.eye(cube.shape[1]),
+                                      wrapped_params(w.parnames), nsteps=8, seed=4)
+        th_chk, ll_chk = md.prior_loglike_batch(c2)
+    assert c2.shape == cube.shape and n >= 8 * len(cube)
+    assert (l2 > lstar).all() and np.array_equal(th_chk, t2) and np.array_equal(ll_chk, l2)
+
+
 def test_pipeline_lanes_give_identical_results_and_order_theta_updates(gpu_required):
     """Device-resident launches alternate between two lanes (streams + buffers).  Either lane must produce the
     same log-L, and a theta upload / prior launch (lane 0's stream) must be seen by a following lane-1 launch."""
