@@ -369,10 +369,15 @@ def main():
         dist.barrier()
     model.dev_sync()
     t0 = time.perf_counter()
+    if world == 1:
+        model.dev_mark(0)                        # HIP event on the stream the kernel is launched on
     for _ in range(args.steps):
         step()
+    if world == 1:
+        model.dev_mark(1)
     model.dev_sync()
     elapsed = time.perf_counter() - t0
+    timed_region_kernel_ms = model.dev_mark_elapsed_ms() / args.steps if world == 1 else None
     if dist:
         dist.barrier()
         tmax = torch.tensor([elapsed], dtype=torch.float64)
@@ -390,7 +395,9 @@ def main():
         # dominant kernel, measured live with HIP events on the stream it is launched on
         tm = model.dev_time_loglike(B, warmup=max(3, args.warmup // 4), iters=max(10, min(args.steps, 200)))
         _, gpu_logl, flags = model.dev_download(B, flags=True)
-        kern_s = tm["kernel_ms_mean"] * 1e-3
+        # the roofline uses the launch duration over the TIMED REGION itself (HIP events around its K launches on
+        # their stream); the per-launch statistics of a separate event-per-launch run are reported beside it
+        kern_s = (timed_region_kernel_ms if timed_region_kernel_ms is not None else tm["kernel_ms_mean"]) * 1e-3
         abytes = algorithmic_bytes_per_launch(w.ndim, w.table.n_epochs, B)
         achieved = abytes / kern_s / 1e9
         out = {
@@ -411,7 +418,9 @@ def main():
                                           "the N=1 equivalent is two_lane_pipelined_evals_per_s of the N=1 line")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.config, B),
-                         "kernel": "loglike_kernel", "kernel_ms_mean": tm["kernel_ms_mean"],
+                         "kernel": "loglike_kernel",
+                         "kernel_ms_timed_region": kern_s * 1e3,     # what `achieved` is computed from
+                         "kernel_ms_mean": tm["kernel_ms_mean"],      # event-per-launch statistics (separate run)
                          "kernel_ms_min": tm["kernel_ms_min"], "kernel_ms_median": tm["kernel_ms_median"],
                          "algorithmic_bytes_per_launch": abytes,
                          "points_per_block": tm["points_per_block"], "blocks": tm["blocks"],

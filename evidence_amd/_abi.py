@@ -111,6 +111,8 @@ PROTOTYPES = {
     "rvll_dev_download": (C.c_int, [Handle, C.c_int64, _dp, _dp, _ip]),
     "rvll_dev_sync": (C.c_int, [Handle]),
     "rvll_dev_flip_lane": (C.c_int, [Handle]),
+    "rvll_dev_mark": (C.c_int, [Handle, C.c_int32]),
+    "rvll_dev_mark_elapsed": (C.c_int, [Handle, _dp]),
     "rvll_dev_time_loglike": (C.c_int, [Handle, C.c_int64, C.c_int32, C.c_int32, C.POINTER(Timing)]),
     "rvll_set_points_per_block": (C.c_int, [Handle, C.c_int32]),
     "rvll_comm_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),

@@ -192,6 +192,8 @@ struct rvll_handle {
     int32_t* d_walk_wrapped = nullptr;
     unsigned long long* d_walk_ncalls = nullptr;
 
+    hipEvent_t marks[2] = {nullptr, nullptr};   // rvll_dev_mark: HIP events on lane 0's stream
+
     // geometry
     int pb_override = 0;
     std::unordered_map<long long, int> geo;     // batch size -> points per workgroup chosen for it
@@ -559,6 +561,7 @@ int rvll_destroy(rvll_handle* h)
     dev_free(h->d_gather_theta);
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
+    for (auto& e : h->marks) if (e) (void)hipEventDestroy(e);
     if (h->srv_stream) (void)hipStreamDestroy(h->srv_stream);
     if (h->srv) (void)hipHostFree(h->srv);
     dev_free(h->d_srv_out);
@@ -808,6 +811,28 @@ int rvll_dev_download(rvll_handle* h, int64_t B, double* theta, double* logL, in
         if (flags) HIP_TRY(hipMemcpyAsync(flags, h->d_flags2[h->logl_last], nf, hipMemcpyDeviceToHost, h->compute));
     }
     HIP_TRY(hipStreamSynchronize(h->compute));
+    return RVLL_OK;
+}
+
+int rvll_dev_mark(rvll_handle* h, int32_t which)
+{
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (which < 0 || which > 1) return fail(RVLL_E_INVALID, "which must be 0 (start) or 1 (stop)");
+    if (!h->marks[which]) HIP_TRY(hipEventCreate(&h->marks[which]));
+    HIP_TRY(hipEventRecord(h->marks[which], h->compute));
+    return RVLL_OK;
+}
+
+int rvll_dev_mark_elapsed(rvll_handle* h, double* ms)
+{
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!ms || !h->marks[0] || !h->marks[1]) return fail(RVLL_E_INVALID, "both marks must have been recorded");
+    HIP_TRY(hipEventSynchronize(h->marks[1]));
+    float f = 0.f;
+    HIP_TRY(hipEventElapsedTime(&f, h->marks[0], h->marks[1]));
+    *ms = (double)f;
     return RVLL_OK;
 }
 

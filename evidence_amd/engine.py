@@ -279,6 +279,15 @@ class GpuRVModel:
             _abi.as_ip(fl) if flags else None))
         return th, ll, fl
 
+    def dev_mark(self, which):
+        """Record HIP event 0 (start) or 1 (stop) on the compute stream."""
+        _abi.check(self._lib.rvll_dev_mark(self._h, int(which)))
+
+    def dev_mark_elapsed_ms(self):
+        ms = C.c_double()
+        _abi.check(self._lib.rvll_dev_mark_elapsed(self._h, C.byref(ms)))
+        return ms.value
+
     def dev_time_loglike(self, n, warmup=3, iters=20):
         t = _abi.Timing()
         _abi.check(self._lib.rvll_dev_time_loglike(self._h, int(n), int(warmup), int(iters), C.byref(t)))

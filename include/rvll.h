@@ -269,6 +269,12 @@ int rvll_dev_flip_lane(rvll_handle* h);
 int rvll_dev_time_loglike(rvll_handle* h, int64_t B, int32_t warmup, int32_t iters,
                           rvll_timing* out);
 
+/* Two HIP events on the compute stream (lane 0): record which = 0 before and which = 1 after a sequence of
+ * device-resident launches; rvll_dev_mark_elapsed waits for the second and returns the time between them as the
+ * device saw it (what bench.py divides by its step count for the roofline's kernel duration).               */
+int rvll_dev_mark(rvll_handle* h, int32_t which);
+int rvll_dev_mark_elapsed(rvll_handle* h, double* ms);
+
 /* ---- launch geometry ------------------------------------------------------ */
 /* points_per_block <= 0 restores the built-in heuristic.                     */
 int rvll_set_points_per_block(rvll_handle* h, int32_t points_per_block);
