@@ -151,18 +151,19 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// A workgroup owns 256 consecutive bins of one run (wave w: bins tile_lo + 64 w ..) and streams the run's rows
-// kRowsPerThread * 256 at a time.  Phase 1, one thread per row: the union of the row's spans becomes one 64-bit
-// coverage mask per wave (index work, vectorised over rows) and goes to LDS with the row's contribution; the
-// spans of the NEXT chunk are requested before that, so their latency hides behind phase 2.  Phase 2, per wave:
-// the rows with a non-zero mask are visited in row order; the mask of the visited row is moved to a scalar
-// register pair (v_readlane), its contribution is an LDS broadcast, and the subtraction runs under EXEC = mask,
-// which is bit-identical to skipping it in the uncovered lanes.  Groups of 64 rows that mostly touch the wave
-// take a straight-line path over all 64 (an empty mask changes nothing); sparse groups walk the set bits.
-// The LDS stage is double-buffered, so one barrier per chunk suffices.  The per-bin fold stays strictly
-// sequential; its cost is ~3 vector instructions per (row, wave) the row touches.
+// A workgroup owns 256 consecutive bins of one run (consumer wave w: bins tile_lo + 64 w ..) and streams the run's
+// rows kRowsPerThread * 256 at a time.  It has 512 threads: waves 4-7 are PRODUCERS — one thread per row, the
+// union of the row's spans becomes one 64-bit coverage mask per consumer wave (index work, vectorised over rows)
+// and goes to LDS with the row's contribution; the spans are requested one chunk ahead — and waves 0-3 are the
+// CONSUMERS that fold: the rows with a non-zero mask are visited in row order; the mask of the visited row is
+// moved to a scalar register pair (v_readlane), its contribution is an LDS broadcast, and the subtraction runs
+// under EXEC = mask, which is bit-identical to skipping it in the uncovered lanes.  Groups of 64 rows that mostly
+// touch the wave take a straight-line path over all 64 (an empty mask changes nothing); sparse groups walk the
+// set bits.  The LDS stage is double-buffered: the producers fill stage i+1 while the consumers fold stage i, one
+// barrier per chunk.  The per-bin fold stays strictly sequential; its cost is ~3 vector instructions per
+// (row, wave) the row touches.
 template <int NP>
-__global__ __launch_bounds__(kThreads)
+__global__ __launch_bounds__(2 * kThreads)
 void fip_accumulate_kernel(const int2* __restrict__ spans, const double* __restrict__ contrib,
                            const long long* __restrict__ run_start, long long n_rows, int nfreq,
                            double* __restrict__ fapnu)
@@ -173,13 +174,15 @@ void fip_accumulate_kernel(const int2* __restrict__ spans, const double* __restr
     __shared__ double s_c[2][kChunk];
     __shared__ int s_any[2][kWaves];
 
-    const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid >> 6;
+    // 512 threads: waves 0-3 own the 256 bins (the fold), waves 4-7 prepare the NEXT chunk's masks meanwhile
+    const bool producer = threadIdx.x >= kThreads;
+    const int tid = threadIdx.x & (kThreads - 1), lane = tid & (kWave - 1), wave = tid >> 6;
     const int run = blockIdx.y;
     const int tile_lo = blockIdx.x * kThreads;
     const int tile_hi = min(tile_lo + kThreads, nfreq);
     const int bin = tile_lo + tid;
     const long long r0 = run_start[run], r1 = run_start[run + 1];
-    double v = bin < nfreq ? fapnu[(long long)run * nfreq + bin] : 0.;
+    double v = (!producer && bin < nfreq) ? fapnu[(long long)run * nfreq + bin] : 0.;
 
     int2 sp_next[kRowsPerThread][NP];
     double c_next[kRowsPerThread];
@@ -193,10 +196,8 @@ void fip_accumulate_kernel(const int2* __restrict__ spans, const double* __restr
             c_next[q] = ok ? contrib[row] : 0.;
         }
     };
-    fetch(r0);
-
-    int buf = 0;
-    for (long long base = r0; base < r1; base += kChunk, buf ^= 1) {
+    // phase 1 of one chunk into stage `b`: registers -> per-wave coverage masks + contributions in LDS
+    auto produce = [&](int b) {
         int2 sp[kRowsPerThread][NP];
         double c[kRowsPerThread];
 #pragma unroll
@@ -205,9 +206,6 @@ void fip_accumulate_kernel(const int2* __restrict__ spans, const double* __restr
             for (int j = 0; j < NP; ++j) sp[q][j] = sp_next[q][j];
             c[q] = c_next[q];
         }
-        if (base + kChunk < r1) fetch(base + kChunk);
-
-        // phase 1
         bool any = false;
 #pragma unroll
         for (int q = 0; q < kRowsPerThread; ++q) {
@@ -226,45 +224,65 @@ void fip_accumulate_kernel(const int2* __restrict__ spans, const double* __restr
                 any = true;
             }
 #pragma unroll
-            for (int w = 0; w < kWaves; ++w) s_mask[buf][w][tid + q * kThreads] = m[w];
-            s_c[buf][tid + q * kThreads] = c[q];
+            for (int w = 0; w < kWaves; ++w) s_mask[b][w][tid + q * kThreads] = m[w];
+            s_c[b][tid + q * kThreads] = c[q];
         }
         const unsigned long long wave_any = __ballot(any);
-        if (lane == 0) s_any[buf][wave] = wave_any != 0ull;
-        lds_barrier();
-        if (!(s_any[buf][0] | s_any[buf][1] | s_any[buf][2] | s_any[buf][3])) continue;   // no row touches this tile
+        if (lane == 0) s_any[b][wave] = wave_any != 0ull;
+    };
 
-        // phase 2
-        for (int g = 0; g < kChunk / kWave; ++g) {
-            const unsigned long long mv = s_mask[buf][wave][g * kWave + lane];
-            const double* cg = &s_c[buf][g * kWave];
-            unsigned long long todo = __ballot(mv != 0ull);
-            if (__popcll(todo) >= kDenseHits) {
-                double cn[8];                           // contributions are fetched two batches ahead of their use
+    if (producer) {
+        fetch(r0);
+        if (r0 < r1) {
+                    produce(0);                                   // chunk 0 into stage 0
+            if (r0 + kChunk < r1) fetch(r0 + kChunk);
+        }
+    }
+    lds_barrier();
+
+    int buf = 0;
+    for (long long base = r0; base < r1; base += kChunk, buf ^= 1) {
+        if (producer) {
+            // chunk i+1 goes into the other stage while the consumers fold chunk i; its spans were requested one
+            // iteration ago, the ones of chunk i+2 are requested now
+            if (base + kChunk < r1) {
+                produce(buf ^ 1);
+                if (base + 2 * kChunk < r1) fetch(base + 2 * kChunk);
+            }
+        } else if (s_any[buf][0] | s_any[buf][1] | s_any[buf][2] | s_any[buf][3]) {
+            // phase 2
+            for (int g = 0; g < kChunk / kWave; ++g) {
+                const unsigned long long mv = s_mask[buf][wave][g * kWave + lane];
+                const double* cg = &s_c[buf][g * kWave];
+                unsigned long long todo = __ballot(mv != 0ull);
+                if (__popcll(todo) >= kDenseHits) {
+                    double cn[8];                       // contributions are fetched two batches ahead of their use
 #pragma unroll
-                for (int i = 0; i < 8; ++i) cn[i] = cg[i];
+                    for (int i = 0; i < 8; ++i) cn[i] = cg[i];
 #pragma unroll
-                for (int h = 0; h < kWave; h += 4) {
-                    const double c0 = cn[0], c1 = cn[1], c2 = cn[2], c3 = cn[3];
+                    for (int h = 0; h < kWave; h += 4) {
+                        const double c0 = cn[0], c1 = cn[1], c2 = cn[2], c3 = cn[3];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) cn[i] = cn[i + 4];
-                    if (h + 8 < kWave) {
+                        for (int i = 0; i < 4; ++i) cn[i] = cn[i + 4];
+                        if (h + 8 < kWave) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) cn[4 + i] = cg[h + 8 + i];
+                            for (int i = 0; i < 4; ++i) cn[4 + i] = cg[h + 8 + i];
+                        }
+                        masked_sub4(v, lane_u64(mv, h), c0, lane_u64(mv, h + 1), c1, lane_u64(mv, h + 2), c2,
+                                    lane_u64(mv, h + 3), c3);
                     }
-                    masked_sub4(v, lane_u64(mv, h), c0, lane_u64(mv, h + 1), c1, lane_u64(mv, h + 2), c2,
-                                lane_u64(mv, h + 3), c3);
-                }
-            } else {
-                while (todo) {
-                    const int h = __builtin_ctzll(todo);
-                    todo &= todo - 1ull;
-                    masked_sub(v, lane_u64(mv, h), cg[h]);
+                } else {
+                    while (todo) {
+                        const int h = __builtin_ctzll(todo);
+                        todo &= todo - 1ull;
+                        masked_sub(v, lane_u64(mv, h), cg[h]);
+                    }
                 }
             }
         }
+        lds_barrier();                                    // stage buf is free again, stage buf^1 is complete
     }
-    if (bin < nfreq) fapnu[(long long)run * nfreq + bin] = v;
+    if (!producer && bin < nfreq) fapnu[(long long)run * nfreq + bin] = v;
 }
 
 template <int NP>
@@ -272,7 +290,7 @@ hipError_t launch_accumulate(const int2* spans, const double* contrib, const lon
                              int nfreq, int n_runs, double* fapnu, hipStream_t s)
 {
     const dim3 grid((unsigned)((nfreq + kThreads - 1) / kThreads), (unsigned)n_runs);
-    hipLaunchKernelGGL(fip_accumulate_kernel<NP>, grid, dim3(kThreads), 0, s, spans, contrib, run_start, n_rows,
+    hipLaunchKernelGGL(fip_accumulate_kernel<NP>, grid, dim3(2 * kThreads), 0, s, spans, contrib, run_start, n_rows,
                        nfreq, fapnu);
     return hipGetLastError();
 }
