@@ -43,6 +43,21 @@ def test_walk_invariants(gpu_required, cfg, k):
     assert np.array_equal(c0, cube) and np.array_equal(l0, logl) and n0 == 0   # nsteps = 0: nothing moves
 
 
+@pytest.mark.parametrize("precision", ["mixed", "fp32"])
+def test_walk_and_scalar_server_in_the_reduced_precision_modes(gpu_required, precision):
+    """The walk kernel and the scalar-call server are instantiated per precision mode: same invariants, judged
+    against the batch path of the SAME mode (bit for bit)."""
+    w = make_workload(3)
+    with GpuRVModel(w.fixedpardict, w.table, w.parnames, priordict=w.priordict(), precision=precision) as m:
+        cube, theta, logl, lstar, chol = _start(m, w, 2000, seed=4)
+        c2, t2, l2, n = m.slice_walk(cube, theta, logl, lstar, chol, wrapped_params(m.parnames), nsteps=6, seed=2)
+        th_chk, ll_chk = m.prior_loglike_batch(c2)
+        assert (l2 > lstar).all() and np.array_equal(th_chk, t2) and np.array_equal(ll_chk, l2) and n >= 6 * len(cube)
+        want = m.log_likelihood_batch(t2[:32])
+        m.scalar_server(True)
+        assert np.array_equal(np.array([m.log_likelihood(x) for x in t2[:32]]), want)
+
+
 def test_walk_gives_up_a_move_after_max_rounds_and_accepts_no_wrapping(gpu_required):
     """A tight constraint with max_rounds = 1: most candidates are rejected and the move is given up — the walker
     stays where it was, still above lstar; ncalls counts exactly the one candidate per walker.  wrapped=None works."""
