@@ -1100,6 +1100,51 @@ int rvll_prior_loglike_batch(rvll_handle* h, const double* cube, int64_t B,
         if (theta_out) memcpy(theta_out, host_out + nout, nin);
         return RVLL_OK;
     }
+    // measured (profiles/r01_split_probe.txt): two halves help from 16384 points (+15 %) to 65536 (+35 %); more chunks
+    // lose to the per-copy fixed costs, and at 262144 points the large pageable downloads on two streams collapse
+    int nsplit = (B >= kSplitMinPoints && B <= 131072) ? 2 : 1;
+    if (const char* e = getenv("RVLL_SPLIT")) nsplit = std::max(1, std::min(64, atoi(e)));   // measurement switch
+    if (nsplit > 1 && B >= 2 * nsplit) {
+        // Large host batch: chunks alternate between two streams, software-pipelined by one chunk.  Copies from /
+        // to pageable memory occupy the calling thread, so while it stages the upload of chunk c+1 and the
+        // download of chunk c-1, the GPU runs the kernels of chunk c.
+        int rc = rvll_dev_reserve(h, B);
+        if (rc) return rc;
+        rc = sync_other_lanes(h);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(h->compute));
+        const long long D = h->L.ndim;
+        auto bounds = [&](int c, long long* lo, long long* hi) { *lo = B * c / nsplit; *hi = B * (c + 1) / nsplit; };
+        auto fetch = [&](int c) -> int {
+            long long lo, hi;
+            bounds(c, &lo, &hi);
+            hipStream_t st = h->lanes[c & 1];
+            if (theta_out) HIP_TRY(hipMemcpyAsync(theta_out + lo * D, h->d_theta + lo * D, sizeof(double) * (size_t)((hi - lo) * D), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(logL + lo, h->d_logL2[0] + lo, sizeof(double) * (size_t)(hi - lo), hipMemcpyDeviceToHost, st));
+            if (flags) HIP_TRY(hipMemcpyAsync(flags + lo, h->d_flags2[0] + lo, sizeof(int32_t) * (size_t)(hi - lo), hipMemcpyDeviceToHost, st));
+            return RVLL_OK;
+        };
+        for (int c = 0; c < nsplit; ++c) {
+            long long lo, hi;
+            bounds(c, &lo, &hi);
+            hipStream_t st = h->lanes[c & 1];
+            HIP_TRY(hipMemcpyAsync(h->d_cube + lo * D, cube + lo * D, sizeof(double) * (size_t)((hi - lo) * D), hipMemcpyHostToDevice, st));
+            rvll::PriorArgs pa{h->d_cube + lo * D, h->d_theta + lo * D, hi - lo, h->L.ndim, h->d_priors, h->d_heavy, h->n_heavy};
+            HIP_TRY(rvll::launch_prior(pa, st));
+            rvll::LoglikeArgs a;
+            rc = build_args(h, h->d_theta + lo * D, h->d_logL2[0] + lo, h->d_flags2[0] + lo, hi - lo, &a);
+            if (rc) return rc;
+            HIP_TRY(rvll::launch_loglike(a, st));
+            if (c > 0) { rc = fetch(c - 1); if (rc) return rc; }
+        }
+        rc = fetch(nsplit - 1);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(h->compute));
+        HIP_TRY(hipStreamSynchronize(h->lanes[1]));
+        h->theta_async = false;
+        h->logl_last = 0;
+        return RVLL_OK;
+    }
     int rc = rvll_dev_upload_cube(h, cube, B);
     if (rc) return rc;
     // measured (profiles/r01_fused_probe.txt): one launch saves ~1 us up to a few thousand points; beyond that

@@ -27,3 +27,26 @@ with GpuRVModel(w.fixedpardict, w.table, w.parnames) as m:
             if ref is None:
                 ref = out
             print(f"n={n:7d} {mode:5s} {dt*1e6:8.1f} us  {n/dt:.3e} evals/s  identical={np.array_equal(out, ref)}", flush=True)
+
+# the same for the cube -> theta -> log-L call (cube up, theta and log-L down)
+w = make_workload(3)
+with GpuRVModel(w.fixedpardict, w.table, w.parnames, priordict=w.priordict()) as m:
+    for n in (16384, 65536, 262144):
+        cube = w.sample_cube(n, 2)
+        ref = None
+        for mode in ("1", "2", "4", "8", "default"):
+            if mode == "default":
+                os.environ.pop("RVLL_SPLIT", None)
+            else:
+                os.environ["RVLL_SPLIT"] = mode
+            for _ in range(3):
+                th, ll = m.prior_loglike_batch(cube)
+            reps = 20
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                th, ll = m.prior_loglike_batch(cube)
+            dt = (time.perf_counter() - t0) / reps
+            if ref is None:
+                ref = (th, ll)
+            same = bool(np.array_equal(th, ref[0]) and np.array_equal(ll, ref[1]))
+            print(f"prior+loglike n={n:7d} {mode:7s} {dt*1e6:8.1f} us  {n/dt:.3e} evals/s  identical={same}", flush=True)
