@@ -115,6 +115,7 @@ PROTOTYPES = {
     "rvll_dev_mark_elapsed": (C.c_int, [Handle, _dp]),
     "rvll_dev_time_loglike": (C.c_int, [Handle, C.c_int64, C.c_int32, C.c_int32, C.POINTER(Timing)]),
     "rvll_set_points_per_block": (C.c_int, [Handle, C.c_int32]),
+    "rvll_set_kernel_form": (C.c_int, [Handle, C.c_int32]),
     "rvll_comm_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
     "rvll_comm_init": (C.c_int, [Handle, C.POINTER(C.c_ubyte), C.c_int32, C.c_int32]),
     "rvll_allgather_logl": (C.c_int, [Handle, C.c_int64]),
@@ -125,6 +126,7 @@ PROTOTYPES = {
     "rvll_kep_rv_batch": (C.c_int, [Handle, _dp, C.c_int64, _dp, C.c_int32, C.c_uint32, _dp]),
     "rvll_fip_accumulate": (C.c_int, [C.c_int32, _dp, _dp, C.c_int32, _dp, _dp, C.POINTER(C.c_int64), C.c_int32,
                                       C.c_int32, _dp, C.c_int32, C.POINTER(FipTiming)]),
+    "rvll_dev_trace_loglike": (C.c_int, [Handle, C.c_int64, C.c_int32, C.POINTER(C.c_uint64), C.c_int64, _ip, _ip]),
     "rvll_debug_eval": (C.c_int, [Handle, C.c_int32, _dp, _dp, C.c_int64, _dp]),
     "rvll_last_error": (C.c_char_p, []),
     "rvll_version": (C.c_int, [_ip, _ip]),

@@ -139,6 +139,8 @@ struct rvll_handle {
     rvll_planet* d_planets = nullptr;
     rvll_inst*   d_insts = nullptr;
     rvll_slot*   d_linslots = nullptr;
+    double*      d_layblob = nullptr;       // planets, insts, linslots, drift[4], tref back to back: staged into LDS by the kernels
+    int          form_override = 0;         // RVLL_FORM: 1 = tile kernel only, 2 = CU-wide kernel wherever it fits
 
     // resident epoch table
     int Ne = 0;
@@ -198,7 +200,7 @@ struct rvll_handle {
     int pb_override = 0;
     std::unordered_map<long long, int> geo;     // batch size -> points per workgroup chosen for it
     std::unordered_map<size_t, int> occ_by_lds; // dynamic LDS bytes -> resident workgroups per CU
-    int chunk_items = 4096;
+    int chunk_items = rvll::kTileWindow;
     int n_cu = 256;
 
     // multi-GPU
@@ -342,10 +344,38 @@ int choose_points_per_block(rvll_handle* h, long long B)
     return best;
 }
 
+// The CU-wide form (rvll_kernels.hip, loglike_cu_kernel): 1024-thread workgroups, one per CU at a time, each taking
+// a tile of PB points whose items all sit in LDS.  Chosen when every CU gets enough wave rounds to keep its 16 waves
+// busy (below that the 256-thread tiles pack small batches better) and one point's items fit the LDS budget.  The
+// tile size is the largest that fits, lowered so that the number of tiles is a whole number of rounds over the CUs.
+// Returns the grid (0: use the tile form) and sets a->PB / a->CH.
+int choose_cu_form(rvll_handle* h, long long B, rvll::LoglikeArgs* a)
+{
+    if (h->form_override == 1 || h->pb_override > 0) return 0;
+    const long long wave_rounds_per_cu = B * h->Ne / rvll::kWave / std::max(1, h->n_cu);
+    if (h->form_override != 2 && wave_rounds_per_cu < 96) return 0;
+    const long long ncu = std::min<long long>(h->n_cu, B);
+    const long long ppc = (B + ncu - 1) / ncu;                      // points per CU
+    rvll::LoglikeArgs t = *a;
+    auto fits = [&](int pb) {
+        t.PB = pb; t.CH = (pb * h->Ne + 1) & ~1;
+        return rvll::loglike_lds_bytes(t) <= rvll::kCuLdsBudget;
+    };
+    int pbmax = (int)std::min<long long>(rvll::kCuMaxPoints, ppc);
+    while (pbmax >= 1 && !fits(pbmax)) --pbmax;
+    if (pbmax < 1) return 0;
+    const long long rounds = (ppc + pbmax - 1) / pbmax;             // tiles per CU
+    const int pb = (int)((B + ncu * rounds - 1) / (ncu * rounds));
+    a->PB = pb;
+    a->CH = (pb * h->Ne + 1) & ~1;
+    return (int)((B + pb - 1) / pb);
+}
+
 int build_args(rvll_handle* h, const double* d_theta, double* d_logL, int32_t* d_flags,
-               long long B, rvll::LoglikeArgs* out)
+               long long B, rvll::LoglikeArgs* out, int* cu_grid = nullptr)
 {
     rvll::LoglikeArgs a{};
+    a.layblob = h->d_layblob;
     a.theta = d_theta; a.logL = d_logL; a.flags = d_flags; a.B = B;
     a.t = h->d_t; a.y = h->d_y; a.s2 = h->d_s2; a.inst = h->d_inst; a.linpar = h->d_linpar;
     a.Ne = h->Ne;
@@ -353,13 +383,15 @@ int build_args(rvll_handle* h, const double* d_theta, double* d_logL, int32_t* d
     a.D = h->L.ndim; a.Np = h->L.nplanets; a.Ni = h->L.ninst; a.nlin = h->L.nlinpar;
     a.has_jitter = h->L.has_jitter; a.has_drift = h->L.has_drift;
     a.tref_from_data = h->L.tref_from_data;
-    for (int i = 0; i < 4; ++i) a.drift[i] = h->L.drift[i];
-    a.tref = h->L.tref;
     a.tol = h->L.tol; a.itmax = h->L.itmax; a.precision = h->L.precision;
     a.PB = choose_points_per_block(h, B);
     a.CH = std::min(h->chunk_items, std::max(rvll::kThreads, a.PB * h->Ne));
     a.CH = (a.CH + 1) & ~1;
     a.cte = h->cte;
+    if (cu_grid) {
+        *cu_grid = choose_cu_form(h, B, &a);
+        if (*cu_grid > 0) { *out = a; return RVLL_OK; }
+    }
     // shrink PB until the LDS carve fits the 64 KiB default dynamic limit
     while (a.PB > 1 && rvll::loglike_lds_bytes(a) > 60 * 1024) {
         a.PB -= 1;
@@ -371,6 +403,11 @@ int build_args(rvll_handle* h, const double* d_theta, double* d_logL, int32_t* d
                     a.D, a.Np);
     *out = a;
     return RVLL_OK;
+}
+
+hipError_t launch_form(const rvll::LoglikeArgs& a, int cu_grid, hipStream_t stream)
+{
+    return cu_grid > 0 ? rvll::launch_loglike_cu(a, cu_grid, stream) : rvll::launch_loglike(a, stream);
 }
 
 // fused cube -> theta -> log-L launch: the same arguments plus the prior table and the two row buffers
@@ -542,6 +579,18 @@ int rvll_create(const rvll_layout* layout, const double* time, const double* vra
     }
     CREATE_TRY(hipMalloc(&h->d_insts, sizeof(rvll_inst) * (size_t)layout->ninst));
     CREATE_TRY(hipMemcpy(h->d_insts, h->insts.data(), sizeof(rvll_inst) * (size_t)layout->ninst, hipMemcpyHostToDevice));
+    {
+        std::vector<char> blob;
+        auto append = [&](const void* p, size_t n) { const char* c = static_cast<const char*>(p); blob.insert(blob.end(), c, c + n); };
+        append(h->planets.data(), sizeof(rvll_planet) * h->planets.size());
+        append(h->insts.data(), sizeof(rvll_inst) * h->insts.size());
+        append(h->linslots.data(), sizeof(rvll_slot) * h->linslots.size());
+        append(h->L.drift, sizeof(rvll_slot) * 4);
+        append(&h->L.tref, sizeof(rvll_slot));
+        CREATE_TRY(hipMalloc(&h->d_layblob, std::max<size_t>(blob.size(), 8)));
+        if (!blob.empty()) CREATE_TRY(hipMemcpy(h->d_layblob, blob.data(), blob.size(), hipMemcpyHostToDevice));
+    }
+    if (const char* e = getenv("RVLL_FORM")) h->form_override = !strcmp(e, "tile") ? 1 : !strcmp(e, "cu") ? 2 : 0;
 #undef CREATE_TRY
     *out = h;
     return RVLL_OK;
@@ -568,7 +617,7 @@ int rvll_destroy(rvll_handle* h)
     dev_free(h->d_walk_u); dev_free(h->d_walk_theta); dev_free(h->d_walk_logl); dev_free(h->d_walk_chol);
     dev_free(h->d_walk_wrapped); dev_free(h->d_walk_ncalls);
     dev_free(h->d_t); dev_free(h->d_y); dev_free(h->d_s2); dev_free(h->d_inst); dev_free(h->d_linpar);
-    dev_free(h->d_planets); dev_free(h->d_insts); dev_free(h->d_linslots);
+    dev_free(h->d_planets); dev_free(h->d_insts); dev_free(h->d_linslots); dev_free(h->d_layblob);
     for (int l = 1; l < kMaxLanes; ++l) if (h->lanes[l]) (void)hipStreamDestroy(h->lanes[l]);
     if (h->compute) (void)hipStreamDestroy(h->compute);
     delete h;
@@ -581,6 +630,14 @@ int rvll_set_points_per_block(rvll_handle* h, int32_t points_per_block)
     if (points_per_block > rvll::kMaxPointsPerBlock)
         return fail(RVLL_E_INVALID, "points_per_block > %d", rvll::kMaxPointsPerBlock);
     h->pb_override = points_per_block > 0 ? points_per_block : 0;
+    return RVLL_OK;
+}
+
+int rvll_set_kernel_form(rvll_handle* h, int32_t form)
+{
+    if (!h) return fail(RVLL_E_INVALID, "null handle");
+    if (form < 0 || form > 2) return fail(RVLL_E_INVALID, "form must be 0 (auto), 1 (tile) or 2 (CU-wide)");
+    h->form_override = form;
     return RVLL_OK;
 }
 
@@ -759,9 +816,10 @@ int rvll_dev_loglike(rvll_handle* h, int64_t B)
         h->theta_async = false;
     }
     rvll::LoglikeArgs a;
-    rc = build_args(h, h->d_theta, h->d_logL2[lane], h->d_flags2[lane], B, &a);
+    int cu = 0;
+    rc = build_args(h, h->d_theta, h->d_logL2[lane], h->d_flags2[lane], B, &a, &cu);
     if (rc) return rc;
-    HIP_TRY(rvll::launch_loglike(a, lane_stream(h, lane)));
+    HIP_TRY(launch_form(a, cu, lane_stream(h, lane)));
     h->logl_last = lane;
     return RVLL_OK;
 }
@@ -864,10 +922,11 @@ int rvll_dev_time_loglike(rvll_handle* h, int64_t B, int32_t warmup, int32_t ite
     rvll::LoglikeArgs a;
     rc = sync_other_lanes(h);
     if (rc) return rc;
-    rc = build_args(h, h->d_theta, h->d_logL2[0], h->d_flags2[0], B, &a);
+    int cu = 0;
+    rc = build_args(h, h->d_theta, h->d_logL2[0], h->d_flags2[0], B, &a, &cu);
     if (rc) return rc;
     h->logl_last = 0;
-    for (int i = 0; i < warmup; ++i) HIP_TRY(rvll::launch_loglike(a, h->compute));
+    for (int i = 0; i < warmup; ++i) HIP_TRY(launch_form(a, cu, h->compute));
     std::vector<hipEvent_t> ev((size_t)iters + 1, nullptr);
     int status = RVLL_OK;
     for (auto& e : ev)
@@ -875,7 +934,7 @@ int rvll_dev_time_loglike(rvll_handle* h, int64_t B, int32_t warmup, int32_t ite
     if (status == RVLL_OK) {
         hipError_t e = hipEventRecord(ev[0], h->compute);
         for (int i = 0; i < iters && e == hipSuccess; ++i) {
-            e = rvll::launch_loglike(a, h->compute);
+            e = launch_form(a, cu, h->compute);
             if (e == hipSuccess) e = hipEventRecord(ev[(size_t)i + 1], h->compute);
         }
         if (e == hipSuccess) e = hipStreamSynchronize(h->compute);
@@ -901,9 +960,46 @@ int rvll_dev_time_loglike(rvll_handle* h, int64_t B, int32_t warmup, int32_t ite
         out->launches = iters;
         out->points_per_block = a.PB;
         out->blocks = (int32_t)((B + a.PB - 1) / a.PB);
-        out->threads = rvll::kThreads;
+        out->threads = cu > 0 ? rvll::kCuThreads : rvll::kThreads;
     }
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    return status;
+}
+
+// Diagnostic: ONE launch of the stamped twin of the fp64 log-L kernel over the resident theta (after `warmup`
+// ordinary launches, so the clocks are where a bench run has them); returns kTraceWords stamps per workgroup.
+int rvll_dev_trace_loglike(rvll_handle* h, int64_t B, int32_t warmup, uint64_t* out, int64_t out_words,
+                           int32_t* blocks, int32_t* points_per_block)
+{
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (B < 1 || B > h->cap) return fail(RVLL_E_INVALID, "B %lld outside reserved capacity %lld", (long long)B, h->cap);
+    if (h->L.precision != RVLL_PREC_FP64) return fail(RVLL_E_UNSUPPORTED, "the trace kernel exists for fp64 only");
+    rc = sync_other_lanes(h);
+    if (rc) return rc;
+    rvll::LoglikeArgs a;
+    int cu = 0;
+    rc = build_args(h, h->d_theta, h->d_logL2[0], h->d_flags2[0], B, &a, &cu);
+    if (rc) return rc;
+    const long long nb = (B + a.PB - 1) / a.PB;
+    if (blocks) *blocks = (int32_t)nb;
+    if (points_per_block) *points_per_block = a.PB;
+    if (!out) return RVLL_OK;                               // size query
+    const long long words = nb * rvll::kTraceWords;
+    if (out_words < words) return fail(RVLL_E_INVALID, "trace buffer too small: %lld < %lld words", (long long)out_words, words);
+    unsigned long long* d_trace = nullptr;
+    HIP_TRY(hipMalloc(&d_trace, sizeof(unsigned long long) * (size_t)words));
+    int status = RVLL_OK;
+    hipError_t e = hipMemsetAsync(d_trace, 0, sizeof(unsigned long long) * (size_t)words, h->compute);
+    for (int i = 0; i < warmup && e == hipSuccess; ++i) e = launch_form(a, cu, h->compute);
+    a.trace = d_trace;
+    if (e == hipSuccess) e = cu > 0 ? rvll::launch_loglike_cu(a, cu, h->compute) : rvll::launch_loglike_trace(a, h->compute);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_trace, sizeof(unsigned long long) * (size_t)words, hipMemcpyDeviceToHost, h->compute);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->compute);
+    if (e != hipSuccess) status = fail(RVLL_E_HIP, "trace launch failed: %s", hipGetErrorString(e));
+    (void)hipStreamSynchronize(h->compute);
+    dev_free(d_trace);
+    h->logl_last = 0;
     return status;
 }
 
@@ -1008,9 +1104,10 @@ int rvll_loglike_batch(rvll_handle* h, const double* theta, int64_t B, double* l
         double* out_l = static_cast<double*>(h->pin_out_dev);
         int32_t* out_f = reinterpret_cast<int32_t*>(out_l + B);
         rvll::LoglikeArgs a;
-        rc = build_args(h, static_cast<const double*>(h->pin_in_dev), out_l, out_f, B, &a);
+        int cu = 0;
+        rc = build_args(h, static_cast<const double*>(h->pin_in_dev), out_l, out_f, B, &a, &cu);
         if (rc) return rc;
-        HIP_TRY(rvll::launch_loglike(a, h->compute));
+        HIP_TRY(launch_form(a, cu, h->compute));
         HIP_TRY(hipStreamSynchronize(h->compute));
         memcpy(logL, h->pin_out, sizeof(double) * (size_t)B);
         if (flags) memcpy(flags, static_cast<char*>(h->pin_out) + sizeof(double) * (size_t)B, sizeof(int32_t) * (size_t)B);
@@ -1034,9 +1131,10 @@ int rvll_loglike_batch(rvll_handle* h, const double* theta, int64_t B, double* l
             HIP_TRY(hipMemcpyAsync(h->d_theta + lo * D, theta + lo * D, sizeof(double) * (size_t)((hi - lo) * D),
                                    hipMemcpyHostToDevice, st));
             rvll::LoglikeArgs a;
-            rc = build_args(h, h->d_theta + lo * D, h->d_logL2[0] + lo, h->d_flags2[0] + lo, hi - lo, &a);
+            int cu = 0;
+            rc = build_args(h, h->d_theta + lo * D, h->d_logL2[0] + lo, h->d_flags2[0] + lo, hi - lo, &a, &cu);
             if (rc) return rc;
-            HIP_TRY(rvll::launch_loglike(a, st));
+            HIP_TRY(launch_form(a, cu, st));
         }
         HIP_TRY(hipStreamSynchronize(h->lanes[1]));
         h->theta_async = false;
@@ -1132,9 +1230,10 @@ int rvll_prior_loglike_batch(rvll_handle* h, const double* cube, int64_t B,
             rvll::PriorArgs pa{h->d_cube + lo * D, h->d_theta + lo * D, hi - lo, h->L.ndim, h->d_priors, h->d_heavy, h->n_heavy};
             HIP_TRY(rvll::launch_prior(pa, st));
             rvll::LoglikeArgs a;
-            rc = build_args(h, h->d_theta + lo * D, h->d_logL2[0] + lo, h->d_flags2[0] + lo, hi - lo, &a);
+            int cu = 0;
+            rc = build_args(h, h->d_theta + lo * D, h->d_logL2[0] + lo, h->d_flags2[0] + lo, hi - lo, &a, &cu);
             if (rc) return rc;
-            HIP_TRY(rvll::launch_loglike(a, st));
+            HIP_TRY(launch_form(a, cu, st));
             if (c > 0) { rc = fetch(c - 1); if (rc) return rc; }
         }
         rc = fetch(nsplit - 1);

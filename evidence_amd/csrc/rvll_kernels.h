@@ -11,6 +11,10 @@ constexpr int kThreads = 256;          // 4 wave64 per workgroup, one per SIMD
 constexpr int kWave    = 64;
 constexpr int kPlanetFields = 8;       // per (point, planet) scalars kept in LDS
 constexpr int kMaxPointsPerBlock = 32;
+constexpr int kTileWindow = 4096;      // (point, epoch) contributions one 256-thread tile keeps in LDS at a time
+constexpr int kCuThreads = 1024;       // the CU-wide form: one workgroup of 16 waves per CU
+constexpr int kCuMaxPoints = 128;      // points per chunk of the CU-wide form
+constexpr size_t kCuLdsBudget = 156 * 1024;   // of the CU's 160 KiB
 
 // Everything the fused log-L kernel needs; passed by value (kernarg segment).
 struct LoglikeArgs {
@@ -30,10 +34,9 @@ struct LoglikeArgs {
     const rvll_planet* planets;   // [Np]
     const rvll_inst*   insts;     // [Ni]
     const rvll_slot*   linslots;  // [nlin]
+    const double*      layblob;   // planets, insts, linslots, drift[4], tref back to back (staged into LDS by the kernels)
     int D, Np, Ni, nlin;
     int has_jitter, has_drift, tref_from_data;
-    rvll_slot drift[4];
-    rvll_slot tref;
     double tol;
     int    itmax;
     int    precision;        // RVLL_PREC_*
@@ -47,7 +50,19 @@ struct LoglikeArgs {
     const rvll_prior*  priors;      // [D]
     const int32_t*     heavy_dims;  // [n_heavy] parameters with an iterative quantile (Beta, Gamma)
     int                n_heavy;
+    // diagnostic build only (launch_loglike_trace): kTraceWords stamps per workgroup, nullptr otherwise
+    unsigned long long* trace;
 };
+// per-workgroup record of the diagnostic kernels (s_memrealtime, 100 MHz; [7] = HW_ID | XCC_ID << 32):
+//   tile form    [0] start, [1] decode done, [2..5] item loop done per wave, [6] end
+//   CU-wide form [0] start, [1] theta landed (wave 0), [2] staged, [3] decoded, [4] wave 0 out of the items,
+//                [5] every wave out of them, [6] end
+constexpr int kTraceWords = 8;
+hipError_t launch_loglike_trace(const LoglikeArgs& a, hipStream_t stream);
+// The CU-wide form (rvll_kernels.hip, loglike_cu_kernel): `grid` 1024-thread workgroups (one fills a CU), each
+// owning a tile of a.PB consecutive points whose a.PB * a.Ne <= a.CH contributions are all resident in LDS.
+// a.trace != nullptr launches the stamped twin (fp64 only).
+hipError_t launch_loglike_cu(const LoglikeArgs& a, int grid, hipStream_t stream);
 
 size_t loglike_lds_bytes(const LoglikeArgs& a);
 

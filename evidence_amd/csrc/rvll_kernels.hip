@@ -32,6 +32,15 @@ __device__ __forceinline__ double slot_get(const rvll_slot s, const double* th)
     return s.idx >= 0 ? th[s.idx] : s.val;
 }
 
+// the same for a slot staged in LDS: both candidates are read, no dependent branch
+__device__ __forceinline__ double slot_lds(const rvll_slot* s, const double* th)
+{
+    const int idx = s->idx;
+    const double v = s->val;
+    const double tv = th[idx >= 0 ? idx : 0];
+    return idx >= 0 ? tv : v;
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll
@@ -39,10 +48,56 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;
 }
 
+// The value `off` lanes further up, for the lanes a wave_sum tree still needs at that step (lane < off), without
+// the LDS crossbar: v_permlane32_swap / v_permlane16_swap (gfx950) exchange the upper half of one register with the
+// lower half of another (32- or 16-lane halves), row_shl DPP shifts within a 16-lane row.  ~10 cycles per step
+// instead of ~120 for a ds_bpermute pair — the reduction of a tile is a serial tail nothing else overlaps.
+__device__ __forceinline__ double lanes_up_32(double v)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const auto a = __builtin_amdgcn_permlane32_swap((unsigned)u, (unsigned)u, false, false);
+    const auto b = __builtin_amdgcn_permlane32_swap((unsigned)(u >> 32), (unsigned)(u >> 32), false, false);
+    return __builtin_bit_cast(double, ((unsigned long long)b[1] << 32) | a[1]);
+}
+__device__ __forceinline__ double lanes_up_16(double v)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const auto a = __builtin_amdgcn_permlane16_swap((unsigned)u, (unsigned)u, false, false);
+    const auto b = __builtin_amdgcn_permlane16_swap((unsigned)(u >> 32), (unsigned)(u >> 32), false, false);
+    return __builtin_bit_cast(double, ((unsigned long long)b[1] << 32) | a[1]);
+}
+template <int N>
+__device__ __forceinline__ double lanes_up_row(double v)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const int l = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, 0x100 + N, 0xf, 0xf, true);          // row_shl:N
+    const int h = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), 0x100 + N, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)h << 32) | (unsigned)l);
+}
+// wave_sum's tree, valid in LANE 0 only (the other lanes hold partial garbage): same additions, same order
+__device__ __forceinline__ double wave_sum_lane0(double v)
+{
+    v += lanes_up_32(v);
+    v += lanes_up_16(v);
+    v += lanes_up_row<8>(v);
+    v += lanes_up_row<4>(v);
+    v += lanes_up_row<2>(v);
+    v += lanes_up_row<1>(v);
+    return v;
+}
+
 // LDS carve-up, all in units of doubles except the int tail.
+constexpr int kPlanetDoubles = (int)(sizeof(rvll_planet) / sizeof(double));
+constexpr int kInstDoubles   = (int)(sizeof(rvll_inst) / sizeof(double));
+constexpr int kSlotDoubles   = (int)(sizeof(rvll_slot) / sizeof(double));
+static_assert(sizeof(rvll_planet) % 8 == 0 && sizeof(rvll_inst) % 8 == 0 && sizeof(rvll_slot) == 16, "layout structs are copied as doubles");
 struct Carve {
-    int theta, pp, ins, dr, lin, acc, contrib, ints, total_doubles;
+    int theta, pp, ins, dr, lin, acc, lay, contrib, ints, total_doubles;
 };
+__host__ __device__ inline int layout_doubles(int Np, int Ni, int nlin)
+{
+    return Np * kPlanetDoubles + Ni * kInstDoubles + (nlin + 5) * kSlotDoubles;   // + the four drift slots and tref
+}
 __host__ __device__ inline Carve carve(int PB, int D, int Np, int Ni, int nlin, int CH)
 {
     Carve c;
@@ -54,9 +109,10 @@ __host__ __device__ inline Carve carve(int PB, int D, int Np, int Ni, int nlin, 
     c.dr = o;      o += PB * 6;
     c.lin = o;     o += PB * nlin;
     c.acc = o;     o += PB;
+    c.lay = o;     o += layout_doubles(Np, Ni, nlin);   // the layout structs, staged once per workgroup
     o = (o + 1) & ~1;
     c.contrib = o; o += CH;
-    c.ints = o;    // ints: nfail[1] pad[1] pflags[PB] anyfail[PB] jfail[PB*Np]
+    c.ints = o;    // ints: nfail[1] ticket[1] pflags[PB] anyfail[PB] jfail[PB*Np]
     const int nints = 2 + 2 * PB + PB * Np;
     o += (nints + 1) / 2;
     c.total_doubles = o;
@@ -289,173 +345,313 @@ __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx&
     }
 }
 
-// One tile of live points [p0, p0 + npts) by one 256-thread workgroup: stage, decode, items, reduce, write.
-// Shared by the batch kernel (tile = blockIdx) and the scalar-call server (one point per request).
-template <int PREC, bool FUSED>
-__device__ __forceinline__ __attribute__((flatten)) void loglike_tile(const LoglikeArgs& __restrict__ a, double* __restrict__ smem, long long p0, int npts)
+#ifndef RVLL_DECODE_INLINE
+#define RVLL_DECODE_INLINE __forceinline__
+#endif
+// LDS views of one workgroup's tile (carve()).
+struct TileLds {
+    double *theta_s, *pp, *ins, *dr, *lin, *acc, *lay, *contrib;
+    int *nfail, *ticket, *pflags, *anyfail, *jfail;
+};
+__device__ __forceinline__ TileLds tile_views(const LoglikeArgs& a, double* smem)
 {
     const Carve cv = carve(a.PB, a.D, a.Np, a.Ni, a.nlin, a.CH);
-    double* theta_s = smem + cv.theta;
-    double* pp      = smem + cv.pp;
-    double* ins     = smem + cv.ins;
-    double* dr      = smem + cv.dr;
-    double* lin     = smem + cv.lin;
-    double* acc     = smem + cv.acc;
-    double* contrib = smem + cv.contrib;
-    int*    ints    = reinterpret_cast<int*>(smem + cv.ints);
-    int*    nfail   = ints;
-    int*    pflags  = ints + 2;
-    int*    anyfail = pflags + a.PB;
-    int*    jfail   = anyfail + a.PB;
+    TileLds L;
+    L.theta_s = smem + cv.theta;  L.pp = smem + cv.pp;    L.ins = smem + cv.ins;  L.dr = smem + cv.dr;
+    L.lin = smem + cv.lin;        L.acc = smem + cv.acc;  L.lay = smem + cv.lay;  L.contrib = smem + cv.contrib;
+    int* ints = reinterpret_cast<int*>(smem + cv.ints);
+    L.nfail = ints;  L.ticket = ints + 1;  L.pflags = ints + 2;  L.anyfail = L.pflags + a.PB;  L.jfail = L.anyfail + a.PB;
+    return L;
+}
 
+// 1. stage the tile's theta rows (one contiguous, coalesced span) + the layout structs + init.  Fused form: the rows
+//    are unit-cube coordinates and go through the prior transform on the way in (light kinds element by element,
+//    then the iterative kinds compacted so that consecutive lanes all run a solve); theta is written back.
+template <bool FUSED, int NT>
+__device__ __forceinline__ void tile_stage(const LoglikeArgs& __restrict__ a, const TileLds& L, long long p0, int npts,
+                                           unsigned long long* stamp = nullptr)
+{
+    const int tid = threadIdx.x;
+    if (FUSED) {
+        const double* src = a.cube + p0 * a.D;
+        double* dst = a.theta_out + p0 * a.D;
+        for (int i = tid; i < npts * a.D; i += NT) {
+            const int pl = i / a.D, d = i - pl * a.D;
+            if (prior_is_heavy(a.priors[d].kind)) continue;
+            const double v = prior_light(a.priors, a.D, src + pl * a.D, d);
+            L.theta_s[i] = v;
+            dst[i] = v;
+        }
+        for (int i = tid; i < npts * a.n_heavy; i += NT) {
+            const int pl = i / a.n_heavy;
+            const int d = a.heavy_dims[i - pl * a.n_heavy];
+            const double v = prior_heavy(a.priors[d], src[pl * a.D + d]);
+            L.theta_s[pl * a.D + d] = v;
+            dst[pl * a.D + d] = v;
+        }
+    } else {
+        const double* src = a.theta + p0 * a.D;
+        for (int i = tid; i < npts * a.D; i += NT) L.theta_s[i] = src[i];
+        if (stamp && tid == 0) {                    // diagnostic builds: theta has landed in this wave
+            __builtin_amdgcn_s_waitcnt(0);
+            *stamp = __builtin_amdgcn_s_memrealtime();
+        }
+    }
+    // the layout structs (planets, instruments, linear-term slots: one device blob) ride along, so that the decode
+    // step reads LDS only — as dependent global loads they were most of a workgroup's prologue
+    for (int i = tid; i < layout_doubles(a.Np, a.Ni, a.nlin); i += NT) L.lay[i] = a.layblob[i];
+    for (int i = tid; i < npts; i += NT) { L.acc[i] = 0.; L.pflags[i] = 0; L.anyfail[i] = 0; }
+    for (int i = tid; i < npts * a.Np; i += NT) L.jfail[i] = 0x7fffffff;
+    if (tid == 0) { L.nfail[0] = 0; L.ticket[0] = 0; }
+}
+
+// 2. decode per-point scalars once (rvmodel:412-456, :181-192, :242-260): one lane per (point, planet) from the
+//    front of the workgroup, one lane per point for the instrument / drift / linear terms from its back, so the two
+//    kinds of work sit in different waves whenever the tile leaves room
+template <int NT>
+__device__ RVLL_DECODE_INLINE void tile_decode(const LoglikeArgs& __restrict__ a, const TileLds& L, int npts)
+{
+    const int tid = threadIdx.x;
+    const rvll_planet* lp = reinterpret_cast<const rvll_planet*>(L.lay);
+    const rvll_inst*   li = reinterpret_cast<const rvll_inst*>(L.lay + a.Np * kPlanetDoubles);
+    const rvll_slot*   ll = reinterpret_cast<const rvll_slot*>(L.lay + a.Np * kPlanetDoubles + a.Ni * kInstDoubles);
+    for (int wk = tid; wk < npts * a.Np; wk += NT) {
+        const int pl = wk / a.Np;
+        const int k  = wk - pl * a.Np;
+        const double* th = L.theta_s + pl * a.D;
+        const rvll_planet& d = lp[k];
+        const double kraw = slot_lds(&d.k, th);
+        const double praw = slot_lds(&d.p, th);
+        const double K = d.k_kind == RVLL_K_LOGK1 ? exp(kraw) : kraw;
+        const double Pd = d.p_kind == RVLL_P_LOGPERIOD ? exp(praw) : praw;
+        const double e1 = slot_lds(&d.e1, th);
+        const double e2 = slot_lds(&d.e2, th);
+        double ecc, omega;
+        if (d.ecc_kind == RVLL_ECC_SECOS_SESIN) {
+            ecc = e1 * e1 + e2 * e2;
+            omega = atan2(e2, e1);
+            if (ecc > 1) atomicOr(&L.pflags[pl], RVLL_FLAG_INVALID_ORBIT);
+        } else if (d.ecc_kind == RVLL_ECC_ECOS_ESIN) {
+            ecc = sqrt(e1 * e1 + e2 * e2);
+            omega = atan2(e2, e1);
+            if (ecc > 1) atomicOr(&L.pflags[pl], RVLL_FLAG_INVALID_ORBIT);
+        } else {
+            ecc = e1;
+            omega = e2;
+        }
+        const double anom = slot_lds(&d.anom, th);
+        const double ma0 = d.anom_kind == RVLL_ANOM_ML0 ? anom - omega : anom;
+        const double ec = ecc > 0.99 ? 0.99 : ecc;                  // trueanomaly.c:11-12
+        double so, co;
+        sincos_f64(omega, so, co);
+        const double q = sqrt((1. - ec) * (1. + ec));
+        double* P = L.pp + (pl * a.Np + k) * kPlanetFields;
+        P[0] = kTwoPi / Pd;
+        P[1] = slot_lds(&d.epoch, th);
+        P[2] = ma0;
+        P[3] = ec;
+        P[4] = K * co;
+        P[5] = K * q * so;
+        P[6] = K * (ecc * co);
+        P[7] = 0.;
+    }
+    for (int pl = NT - 1 - tid; pl < npts; pl += NT) {
+        const double* th = L.theta_s + pl * a.D;
+        for (int i = 0; i < a.Ni; ++i) {
+            L.ins[(pl * a.Ni + i) * 2] = slot_lds(&li[i].offset, th);
+            double j2 = 0.;
+            if (a.has_jitter) { const double jit = slot_lds(&li[i].jitter, th); j2 = jit * jit; }
+            L.ins[(pl * a.Ni + i) * 2 + 1] = j2;
+        }
+        if (a.has_drift) {
+            const rvll_slot* ld = ll + a.nlin;                  // drift[0..3], tref
+            double* d = L.dr + pl * 6;
+            d[0] = slot_lds(&ld[0], th);
+            d[1] = slot_lds(&ld[1], th);
+            d[2] = slot_lds(&ld[2], th);
+            d[3] = slot_lds(&ld[3], th);
+            d[4] = a.tref_from_data ? a.t[0] : slot_lds(&ld[4], th);
+            d[5] = 0.;
+        }
+        for (int k2 = 0; k2 < a.nlin; ++k2) L.lin[pl * a.nlin + k2] = slot_lds(&ll[k2], th);
+    }
+}
+
+// Per-point partial sums of the contributions [lo[k], hi[k]) of up to four points held in contrib[.. - base], each
+// in the fixed order every kernel form uses (lane-strided, then the shuffle tree), so the bits do not depend on the
+// launch geometry.  Four points go through the tree together: one point's six dependent cross-lane steps are
+// ~150 cycles of latency each and nothing else is runnable in a reduction phase.  Unused entries: lo == hi.
+__device__ __forceinline__ void point_partials4(const double* contrib, int base, const int (&lo)[4], const int (&hi)[4],
+                                                int lane, double (&v)[4])
+{
+    // lane-strided sums, four strides of every point in flight per pass.  Out-of-range slots add +0.0, which
+    // changes no partial sum (they start at +0.0 and can never become -0.0).
+    int nmax = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] = 0.; nmax = max(nmax, hi[k] - lo[k]); }
+    for (int t = lane; t < nmax; t += 4 * kWave) {
+        double x[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = lo[k] + t + u * kWave;
+                x[k][u] = i < hi[k] ? contrib[i - base] : 0.;
+            }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (((v[k] + x[k][0]) + x[k][1]) + x[k][2]) + x[k][3];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = wave_sum_lane0(v[k]);
+}
+
+// 4. one log-L per live point
+__device__ __forceinline__ void tile_write_point(const LoglikeArgs& __restrict__ a, const TileLds& L, long long p0, int pl)
+{
+    int f = L.pflags[pl];
+    if (L.anyfail[pl]) f |= RVLL_FLAG_NONCONVERGED;
+    const bool invalid = (f & RVLL_FLAG_INVALID_ORBIT) != 0 && a.Np > 0;
+    a.logL[p0 + pl] = invalid ? -1e30 : a.cte - L.acc[pl];                 // rvmodel:203, :78-80
+    if (a.flags) a.flags[p0 + pl] = f;
+}
+
+// One tile of live points [p0, p0 + npts) by one workgroup of NT threads: stage, decode, items, reduce, write.
+// Shared by the batch kernels (tile = blockIdx), the walk and the scalar-call server (one point per request).
+//   NT = 256, DYN = false  the tile form: four such workgroups per CU, items dealt statically, LDS windows of a.CH
+//                          contributions (<= kTileWindow);
+//   NT = 1024, DYN = true  the CU-wide form: one workgroup fills the CU (16 waves = the same 4 per SIMD), ALL the
+//                          tile's items sit in LDS at once (a.CH >= a.PB * a.Ne, host-checked) and the waves draw
+//                          64-item rounds from an LDS ticket counter, so every wave stays busy until the tile's
+//                          items are gone.  Why: four independent 256-thread workgroups on a CU do not finish
+//                          together — VALU issue is arbitrated by age, the oldest runs fastest — so a launch ended
+//                          with 3, 2, then 1 workgroup per CU for a third of its duration at well under the 4-wave
+//                          issue rate (profiles/r02_wg_trace_cfg3.txt; two launches in flight, which backfill the
+//                          freed slots, ran 20 % faster per launch).
+// Every point's contributions are summed in the same order in both forms — slices at point-local multiples of
+// kTileWindow, each lane-strided then through the shuffle tree — so results are bit-identical across forms, tile
+// sizes and shard sizes.
+// TRACE: diagnostic build (launch_loglike_trace) — a few s_memrealtime stamps per workgroup go to a.trace, a
+// buffer nothing else reads; no stamp executes in the product kernels.
+template <int PREC, bool FUSED, bool TRACE = false, int NT = kThreads, bool DYN = false>
+__device__ __forceinline__ __attribute__((flatten)) void loglike_tile(const LoglikeArgs& __restrict__ a, double* __restrict__ smem, long long p0, int npts)
+{
+    unsigned long long* tr = nullptr;
+    if constexpr (TRACE) {
+        tr = a.trace + (size_t)blockIdx.x * kTraceWords;
+        if (threadIdx.x == 0) {
+            tr[0] = __builtin_amdgcn_s_memrealtime();
+            // s_getreg_b32 simm16 = (size-1) << 11 | offset << 6 | id; HW_REG_HW_ID = 4, HW_REG_XCC_ID = 20
+            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+            const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+            tr[7] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+        }
+    }
+    const TileLds L = tile_views(a, smem);
     const int tid  = threadIdx.x;
     const int lane = tid & (kWave - 1);
     const int wave = tid >> 6;
+    constexpr int NW = NT / kWave;
 
-    // 1. stage this block's theta rows (one contiguous, coalesced span) + init.  Fused form: the rows are
-    //    unit-cube coordinates and go through the prior transform on the way in (light kinds element by
-    //    element, then the iterative kinds compacted so that consecutive lanes all run a solve); theta is
-    //    written back for the caller.
-    {
-        if (FUSED) {
-            const double* src = a.cube + p0 * a.D;
-            double* dst = a.theta_out + p0 * a.D;
-            for (int i = tid; i < npts * a.D; i += kThreads) {
-                const int pl = i / a.D, d = i - pl * a.D;
-                if (prior_is_heavy(a.priors[d].kind)) continue;
-                const double v = prior_light(a.priors, a.D, src + pl * a.D, d);
-                theta_s[i] = v;
-                dst[i] = v;
-            }
-            for (int i = tid; i < npts * a.n_heavy; i += kThreads) {
-                const int pl = i / a.n_heavy;
-                const int d = a.heavy_dims[i - pl * a.n_heavy];
-                const double v = prior_heavy(a.priors[d], src[pl * a.D + d]);
-                theta_s[pl * a.D + d] = v;
-                dst[pl * a.D + d] = v;
-            }
-        } else {
-            const double* src = a.theta + p0 * a.D;
-            for (int i = tid; i < npts * a.D; i += kThreads) theta_s[i] = src[i];
-        }
-        for (int i = tid; i < npts; i += kThreads) { acc[i] = 0.; pflags[i] = 0; anyfail[i] = 0; }
-        for (int i = tid; i < npts * a.Np; i += kThreads) jfail[i] = 0x7fffffff;
-        if (tid == 0) nfail[0] = 0;
-    }
+    // The prologue is a short serial section (a few lanes, long dependent chains).  A young workgroup's waves get
+    // only the issue slots older ones leave (arbitration is by priority, then age), which stretched it 2.5x next
+    // to three workgroups in their item loops: run it at raised priority, the item loop at the default.
+    if constexpr (!DYN) __builtin_amdgcn_s_setprio(3);
+    tile_stage<FUSED, NT>(a, L, p0, npts, TRACE && DYN ? tr + 1 : nullptr);
     __syncthreads();
-
-    // 2. decode per-point scalars once (rvmodel:412-456, :181-192, :242-260)
-    {
-        const int per = a.Np + 1;
-        for (int wk = tid; wk < npts * per; wk += kThreads) {
-            const int pl = wk / per;
-            const int k  = wk - pl * per;
-            const double* th = theta_s + pl * a.D;
-            if (k < a.Np) {
-                const rvll_planet& d = a.planets[k];
-                const double kraw = slot_get(d.k, th);
-                const double praw = slot_get(d.p, th);
-                const double K = d.k_kind == RVLL_K_LOGK1 ? exp(kraw) : kraw;
-                const double Pd = d.p_kind == RVLL_P_LOGPERIOD ? exp(praw) : praw;
-                const double e1 = slot_get(d.e1, th);
-                const double e2 = slot_get(d.e2, th);
-                double ecc, omega;
-                if (d.ecc_kind == RVLL_ECC_SECOS_SESIN) {
-                    ecc = e1 * e1 + e2 * e2;
-                    omega = atan2(e2, e1);
-                    if (ecc > 1) atomicOr(&pflags[pl], RVLL_FLAG_INVALID_ORBIT);
-                } else if (d.ecc_kind == RVLL_ECC_ECOS_ESIN) {
-                    ecc = sqrt(e1 * e1 + e2 * e2);
-                    omega = atan2(e2, e1);
-                    if (ecc > 1) atomicOr(&pflags[pl], RVLL_FLAG_INVALID_ORBIT);
-                } else {
-                    ecc = e1;
-                    omega = e2;
-                }
-                const double anom = slot_get(d.anom, th);
-                const double ma0 = d.anom_kind == RVLL_ANOM_ML0 ? anom - omega : anom;
-                const double ec = ecc > 0.99 ? 0.99 : ecc;                  // trueanomaly.c:11-12
-                double so, co;
-                sincos_f64(omega, so, co);
-                const double q = sqrt((1. - ec) * (1. + ec));
-                double* P = pp + (pl * a.Np + k) * kPlanetFields;
-                P[0] = kTwoPi / Pd;
-                P[1] = slot_get(d.epoch, th);
-                P[2] = ma0;
-                P[3] = ec;
-                P[4] = K * co;
-                P[5] = K * q * so;
-                P[6] = K * (ecc * co);
-                P[7] = 0.;
-            } else {
-                for (int i = 0; i < a.Ni; ++i) {
-                    const rvll_inst& d = a.insts[i];
-                    ins[(pl * a.Ni + i) * 2] = slot_get(d.offset, th);
-                    double j2 = 0.;
-                    if (a.has_jitter) { const double jit = slot_get(d.jitter, th); j2 = jit * jit; }
-                    ins[(pl * a.Ni + i) * 2 + 1] = j2;
-                }
-                if (a.has_drift) {
-                    double* d = dr + pl * 6;
-                    d[0] = slot_get(a.drift[0], th);
-                    d[1] = slot_get(a.drift[1], th);
-                    d[2] = slot_get(a.drift[2], th);
-                    d[3] = slot_get(a.drift[3], th);
-                    d[4] = a.tref_from_data ? a.t[0] : slot_get(a.tref, th);
-                    d[5] = 0.;
-                }
-                for (int k2 = 0; k2 < a.nlin; ++k2) lin[pl * a.nlin + k2] = slot_get(a.linslots[k2], th);
-            }
-        }
-    }
+    if constexpr (TRACE && DYN) { if (tid == 0) tr[2] = __builtin_amdgcn_s_memrealtime(); }
+    tile_decode<NT>(a, L, npts);
     __syncthreads();
+    if constexpr (!DYN) __builtin_amdgcn_s_setprio(0);
+    if constexpr (TRACE) { if (tid == 0) tr[DYN ? 3 : 1] = __builtin_amdgcn_s_memrealtime(); }
 
     // 3. items: flattened (point, epoch) pairs of this block, CH at a time
-    const ItemCtx cx{pp, ins, dr, lin, nfail, anyfail, jfail};
+    const ItemCtx cx{L.pp, L.ins, L.dr, L.lin, L.nfail, L.anyfail, L.jfail};
+    double* contrib = L.contrib;
     const int nitems = npts * a.Ne;
     // LDS windows are cut at point-local positions — whole points while a point fits the window, otherwise
     // every point by itself at multiples of CH — so each point's sum has one order whatever the tiling
     const int wpts = a.Ne <= a.CH ? a.CH / a.Ne : 0;
     for (int base = 0, cend; base < nitems; base = cend) {
         cend = wpts ? min(base + wpts * a.Ne, nitems) : min(base + a.CH, (base / a.Ne + 1) * a.Ne);
-        for (int i = base + tid; i < cend; i += kThreads) {
-            const int pl = i / a.Ne;
-            const int j  = i - pl * a.Ne;
-            contrib[i - base] = eval_item<PREC>(a, cx, pl, j);
+        if constexpr (DYN) {
+            // one window (host-checked): wave rounds of 64 consecutive items, drawn from the ticket counter
+            for (;;) {
+                int r = 0;
+                if (lane == 0) r = atomicAdd(L.ticket, 1);
+                r = __builtin_amdgcn_readfirstlane(r);
+                if (r * kWave >= cend) break;
+                const int i = r * kWave + lane;
+                if (i < cend) {
+                    const int pl = i / a.Ne;
+                    contrib[i] = eval_item<PREC>(a, cx, pl, i - pl * a.Ne);
+                }
+            }
+            if constexpr (TRACE) { if (tid == 0) tr[4] = __builtin_amdgcn_s_memrealtime(); }
+        } else {
+            for (int i = base + tid; i < cend; i += NT) {
+                const int pl = i / a.Ne;
+                const int j  = i - pl * a.Ne;
+                contrib[i - base] = eval_item<PREC>(a, cx, pl, j);
+            }
+            if constexpr (TRACE) { if (lane == 0) tr[2 + wave] = __builtin_amdgcn_s_memrealtime(); }
         }
         __syncthreads();
+        if constexpr (TRACE && DYN) { if (tid == 0) tr[5] = __builtin_amdgcn_s_memrealtime(); }
         // 3b. rare: a solve hit itmax.  The reference aborts that planet's array there
         // and leaves nu = 0 from that epoch on; redo the affected points' items now that
         // the first failing epoch per (point, planet) is known.
-        if (nfail[0] != 0) {
-            for (int i = base + tid; i < cend; i += kThreads) {
+        if (L.nfail[0] != 0) {
+            for (int i = base + tid; i < cend; i += NT) {
                 const int pl = i / a.Ne;
-                if (anyfail[pl]) contrib[i - base] = eval_item<PREC>(a, cx, pl, i - pl * a.Ne);
+                if (L.anyfail[pl]) contrib[i - base] = eval_item<PREC>(a, cx, pl, i - pl * a.Ne);
             }
             __syncthreads();
         }
-        // 3c. per-point partial sums of this chunk, fixed order (deterministic)
+        // 3c. per-point partial sums of this window, fixed order (deterministic): the part of each point that
+        // lies in the window, slice by slice
         const int pl_lo = base / a.Ne;
         const int pl_hi = (cend - 1) / a.Ne;
-        for (int pl = pl_lo + wave; pl <= pl_hi; pl += kThreads / kWave) {
-            const int lo = max(base, pl * a.Ne);
-            const int hi = min(cend, (pl + 1) * a.Ne);
-            double v = 0.;
-            for (int i = lo + lane; i < hi; i += kWave) v += contrib[i - base];
-            v = wave_sum(v);
-            if (lane == 0) acc[pl] += v;
+        const int nslices = (a.Ne + kTileWindow - 1) / kTileWindow;
+        for (int pl0 = pl_lo + wave; pl0 <= pl_hi; pl0 += 4 * NW) {
+            for (int sl = 0; sl < nslices; ++sl) {
+                int lo[4], hi[4];
+                double v[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int pl = pl0 + k * NW;
+                    const int first = pl * a.Ne + sl * kTileWindow;                  // this slice of this point
+                    const int l = max(base, first), h = min(min(cend, (pl + 1) * a.Ne), first + kTileWindow);
+                    const bool any = pl <= pl_hi && l < h;
+                    lo[k] = any ? l : 0;
+                    hi[k] = any ? h : 0;
+                }
+                point_partials4(contrib, base, lo, hi, lane, v);
+                if (lane == 0) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (lo[k] < hi[k]) L.acc[pl0 + k * NW] += v[k];
+                }
+            }
         }
         __syncthreads();
     }
 
-    // 4. one log-L per live point
-    for (int pl = tid; pl < npts; pl += kThreads) {
-        int f = pflags[pl];
-        if (anyfail[pl]) f |= RVLL_FLAG_NONCONVERGED;
-        const bool invalid = (f & RVLL_FLAG_INVALID_ORBIT) != 0 && a.Np > 0;
-        a.logL[p0 + pl] = invalid ? -1e30 : a.cte - acc[pl];              // rvmodel:203, :78-80
-        if (a.flags) a.flags[p0 + pl] = f;
+    for (int pl = tid; pl < npts; pl += NT) tile_write_point(a, L, p0, pl);
+    if constexpr (TRACE) {
+        __syncthreads();
+        if (threadIdx.x == 0) tr[6] = __builtin_amdgcn_s_memrealtime();
     }
+}
+
+// The CU-wide form: one 1024-thread workgroup per tile of a.PB points (loglike_tile, NT = 1024, DYN)
+template <int PREC, bool TRACE>
+__global__ __launch_bounds__(kCuThreads) __attribute__((flatten))
+void loglike_cu_kernel(const LoglikeArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const long long p0 = (long long)blockIdx.x * a.PB;
+    const int npts = (int)min((long long)a.PB, a.B - p0);
+    if (npts <= 0) return;
+    loglike_tile<PREC, false, TRACE, kCuThreads, true>(a, smem, p0, npts);
 }
 
 // 4 workgroups of 256 per CU (4 waves/SIMD): caps the kernel at 128 VGPRs
@@ -468,6 +664,17 @@ void loglike_kernel(const LoglikeArgs a)                                // form 
     const int npts = (int)min((long long)a.PB, a.B - p0);
     if (npts <= 0) return;
     loglike_tile<PREC, FUSED>(a, smem, p0, npts);
+}
+
+// Diagnostic twin of loglike_kernel<RVLL_PREC_FP64, false>: same tile, same launch bounds, plus the stamps.
+__global__ __launch_bounds__(kThreads, 4) __attribute__((flatten))
+void loglike_trace_kernel(const LoglikeArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const long long p0 = (long long)blockIdx.x * a.PB;
+    const int npts = (int)min((long long)a.PB, a.B - p0);
+    if (npts <= 0) return;
+    loglike_tile<RVLL_PREC_FP64, false, true>(a, smem, p0, npts);
 }
 
 // Device-resident slice-sampling walk (rvll_kernels.h, WalkArgs; the scheme of evidence_amd/nested.py
@@ -826,6 +1033,8 @@ void debug_eval_kernel(int op, const double* x, const double* y, long long n, do
         case 9: sincos_f64(a, s, c); rotate_small(b, s, c); r = c; break;
         case 10: r = div_1nr(a, b); break;
         case 11: r = __builtin_amdgcn_rcp(a); break;
+        case 12: r = wave_sum(a); break;                 // lane 0 of every wave: the shuffle tree
+        case 13: r = wave_sum_lane0(a); break;           //                        the same tree without the LDS crossbar
         default: r = NAN; break;
         }
         out[i] = r;
@@ -878,6 +1087,45 @@ hipError_t launch_loglike(const LoglikeArgs& a, hipStream_t stream)
     case RVLL_PREC_FP32:  hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP32, false>), grid, block, lds, stream, a); break;
     default:              hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP64, false>), grid, block, lds, stream, a); break;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_loglike_cu(const LoglikeArgs& a, int grid, hipStream_t stream)
+{
+    if (a.B <= 0) return hipSuccess;
+    const size_t lds = loglike_lds_bytes(a);
+    if (grid < 1 || (long long)grid * a.PB < a.B || a.PB < 1 || a.PB > kCuMaxPoints || (long long)a.CH < (long long)a.PB * a.Ne || lds > kCuLdsBudget ||
+        (a.trace && a.precision != RVLL_PREC_FP64))
+        return hipErrorInvalidValue;
+    static bool attr_set_dev[64] = {};                      // raise the dynamic-LDS limit of every instance once per device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    bool& attr_set = attr_set_dev[dev & 63];
+    if (!attr_set) {
+        const int lim = (int)kCuLdsBudget;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(loglike_cu_kernel<RVLL_PREC_FP64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(loglike_cu_kernel<RVLL_PREC_MIXED, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(loglike_cu_kernel<RVLL_PREC_FP32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(loglike_cu_kernel<RVLL_PREC_FP64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const dim3 g((unsigned)grid), block(kCuThreads);
+    if (a.trace) { hipLaunchKernelGGL((loglike_cu_kernel<RVLL_PREC_FP64, true>), g, block, lds, stream, a); return hipGetLastError(); }
+    switch (a.precision) {
+    case RVLL_PREC_MIXED: hipLaunchKernelGGL((loglike_cu_kernel<RVLL_PREC_MIXED, false>), g, block, lds, stream, a); break;
+    case RVLL_PREC_FP32:  hipLaunchKernelGGL((loglike_cu_kernel<RVLL_PREC_FP32, false>), g, block, lds, stream, a); break;
+    default:              hipLaunchKernelGGL((loglike_cu_kernel<RVLL_PREC_FP64, false>), g, block, lds, stream, a); break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_loglike_trace(const LoglikeArgs& a, hipStream_t stream)
+{
+    if (a.B <= 0) return hipSuccess;
+    if (!a.trace || a.precision != RVLL_PREC_FP64) return hipErrorInvalidValue;
+    const long long blocks = (a.B + a.PB - 1) / a.PB;
+    hipLaunchKernelGGL(loglike_trace_kernel, dim3((unsigned)blocks), dim3(kThreads), loglike_lds_bytes(a), stream, a);
     return hipGetLastError();
 }
 

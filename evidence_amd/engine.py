@@ -293,8 +293,23 @@ class GpuRVModel:
         _abi.check(self._lib.rvll_dev_time_loglike(self._h, int(n), int(warmup), int(iters), C.byref(t)))
         return {f: getattr(t, f) for f, _ in _abi.Timing._fields_}
 
+    def dev_trace_loglike(self, n, warmup=50):
+        """Per-workgroup time stamps of one launch of the diagnostic twin of the fp64 kernel (include/rvll.h):
+        returns (uint64[blocks, 8], points_per_block)."""
+        nb, pb = C.c_int32(), C.c_int32()
+        _abi.check(self._lib.rvll_dev_trace_loglike(self._h, int(n), 0, None, 0, C.byref(nb), C.byref(pb)))
+        out = np.zeros((nb.value, 8), dtype=np.uint64)
+        _abi.check(self._lib.rvll_dev_trace_loglike(self._h, int(n), int(warmup),
+                                                    out.ctypes.data_as(C.POINTER(C.c_uint64)), out.size,
+                                                    C.byref(nb), C.byref(pb)))
+        return out, pb.value
+
     def set_points_per_block(self, pb):
         _abi.check(self._lib.rvll_set_points_per_block(self._h, int(pb)))
+
+    def set_kernel_form(self, form):
+        """Launch form of the log-L kernel: "auto" (by batch size), "tile" or "cu" (include/rvll.h); same bits."""
+        _abi.check(self._lib.rvll_set_kernel_form(self._h, {"auto": 0, "tile": 1, "cu": 2}[form]))
 
     def debug_eval(self, op, x, y=None):
         """Evaluate one device math routine elementwise (include/rvll.h, diagnostics)."""

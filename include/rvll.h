@@ -278,6 +278,11 @@ int rvll_dev_mark_elapsed(rvll_handle* h, double* ms);
 /* ---- launch geometry ------------------------------------------------------ */
 /* points_per_block <= 0 restores the built-in heuristic.                     */
 int rvll_set_points_per_block(rvll_handle* h, int32_t points_per_block);
+/* The log-L kernel has two launch forms with bit-identical results: 256-thread tiles of a few points (small
+ * batches, the walk, the scalar calls) and the CU-wide form (one 1024-thread workgroup per CU walking its share of
+ * the batch; large batches).  0 = choose by batch size (default), 1 = tiles only, 2 = CU-wide wherever it fits.
+ * Environment RVLL_FORM=tile|cu sets the same at rvll_create.                                                  */
+int rvll_set_kernel_form(rvll_handle* h, int32_t form);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI ----------------------- */
 /* 128-byte opaque id created on rank 0 and handed to every rank out of band.  */
@@ -335,9 +340,17 @@ int rvll_fip_accumulate(int32_t device, const double* nua, const double* nub, in
 /* ---- diagnostics -------------------------------------------------------------- */
 /* Evaluate one device math routine elementwise (tests only; no reference counterpart):
  * op 0 sin, 1 cos (rvll sincos), 2 div_exact(x,y), 3 x/y (IEEE), 4 div_fast(x,y),
- * 5 log_pos(x), 6 library log(x), 7 ndtri(x), 8/9 sin/cos after rotate_small by y.  */
+ * 5 log_pos(x), 6 library log(x), 7 ndtri(x), 8/9 sin/cos after rotate_small by y, 10 div_1nr, 11 v_rcp_f64,
+ * 12/13 the wave reduction tree by shuffles / by permlane-swap + DPP (lane 0 of every 64 values).           */
 int rvll_debug_eval(rvll_handle* h, int32_t op, const double* x, const double* y,
                     int64_t n, double* out);
+
+/* One launch of a stamped twin of the fp64 log-L kernel over the resident theta (after `warmup` ordinary
+ * launches): per workgroup 8 words — [0] start, [1] per-point decode done, [2..5] item loop done per wave,
+ * [6] end (constant 100 MHz clock), [7] HW_ID | XCC_ID << 32.  out == NULL only returns the geometry.  The
+ * stamps never execute in the product kernels (no reference counterpart; profiles/ records are made with it). */
+int rvll_dev_trace_loglike(rvll_handle* h, int64_t B, int32_t warmup, uint64_t* out, int64_t out_words,
+                           int32_t* blocks, int32_t* points_per_block);
 
 /* ---- housekeeping ---------------------------------------------------------- */
 const char* rvll_last_error(void);

@@ -87,3 +87,19 @@ def test_ndtri_against_scipy(dev):
     err = np.abs(got[fin] - ref[fin]) / np.maximum(np.abs(ref[fin]), 1e-300)
     err = np.where(ref[fin] == 0, np.abs(got[fin]), err)
     assert err.max() <= 1e-13, float(err.max())
+
+
+def test_lane0_tree_without_lds_crossbar_is_the_shuffle_tree(dev):
+    """The per-point reduction ends in a 6-step tree over the wave.  The kernels take lane 0's value from a
+    v_permlane32_swap / v_permlane16_swap / row_shl-DPP form of it; it must be the shuffle tree bit for bit, and
+    both must be the tree as written: v[i] += v[i + off] for off = 32, 16, 8, 4, 2, 1."""
+    rng = np.random.default_rng(12)
+    n = 256 * 512
+    x = rng.normal(0, 1, n) * 10.0 ** rng.integers(-12, 12, n)
+    shfl = dev.debug_eval(12, x)[::64]
+    fast = dev.debug_eval(13, x)[::64]
+    v = x.reshape(-1, 64).copy()
+    for off in (32, 16, 8, 4, 2, 1):
+        v[:, :off] = v[:, :off] + v[:, off:2 * off]
+    assert np.array_equal(shfl, v[:, 0])
+    assert np.array_equal(fast, v[:, 0])
