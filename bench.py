@@ -242,19 +242,27 @@ def run_extras(out, model, w, theta, B, with_cpu):
         model.dev_sync()
         out["two_lane_pipelined_evals_per_s"] = 1000 * B / (time.perf_counter() - t1)
 
-    def prior_plus_loglike():             # cube -> theta -> log-L all on the device: two launches, and one
+    def prior_plus_loglike():             # cube -> theta -> log-L all on the device
         model.set_priors(w.priordict())
-        model.dev_fill_cube(B, seed=99)
-        for key, step in (("prior_plus_loglike_evals_per_s", lambda: (model.dev_prior(B), model.dev_loglike(B))),
-                          ("prior_plus_loglike_one_launch_evals_per_s", lambda: model.dev_prior_loglike(B))):
+        def timed(n, step, reps):
+            model.dev_fill_cube(n, seed=99)
             for _ in range(5):
                 step()
             model.dev_sync()
             t1 = time.perf_counter()
-            for _ in range(50):
+            for _ in range(reps):
                 step()
             model.dev_sync()
-            out[key] = 50 * B / (time.perf_counter() - t1)
+            return reps * n / (time.perf_counter() - t1)
+        out["prior_plus_loglike_evals_per_s"] = timed(B, lambda: (model.dev_prior(B), model.dev_loglike(B)), 50)
+        # a sampler's proposal round: a small batch, where a launch is a large part of the step — the prior transform
+        # in the log-L tile's staging step (one launch) against prior kernels + log-L kernel; a sync per step, as a
+        # sampler that looks at every result would have
+        small = 2048
+        out["small_batch_prior_plus_loglike"] = {
+            "points": small,
+            "one_launch_evals_per_s": timed(small, lambda: (model.dev_prior_loglike(small), model.dev_sync()), 200),
+            "two_launch_evals_per_s": timed(small, lambda: (model.dev_prior(small), model.dev_loglike(small), model.dev_sync()), 200)}
 
     def scalar_calls():                   # PolyChord's form, one theta per call: launch + sync vs the persistent kernel
         x0, lat = theta[0], {}

@@ -116,6 +116,7 @@ PROTOTYPES = {
     "rvll_dev_time_loglike": (C.c_int, [Handle, C.c_int64, C.c_int32, C.c_int32, C.POINTER(Timing)]),
     "rvll_set_points_per_block": (C.c_int, [Handle, C.c_int32]),
     "rvll_set_kernel_form": (C.c_int, [Handle, C.c_int32]),
+    "rvll_set_slim_table_range": (C.c_int, [Handle, C.c_double]),
     "rvll_comm_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
     "rvll_comm_init": (C.c_int, [Handle, C.POINTER(C.c_ubyte), C.c_int32, C.c_int32]),
     "rvll_allgather_logl": (C.c_int, [Handle, C.c_int64]),

@@ -159,6 +159,11 @@ struct rvll_handle {
     std::vector<double*> d_tables;
     std::vector<double> table_err;              // measured quintic-interpolant error per parameter (NaN: no table)
     std::vector<int> table_direct;              // per parameter: evaluated by verified interpolation alone
+    bool all_direct = true;                     // every Beta / Gamma prior has a verified table: the slim prior stage applies
+    double slim_umax = 0.;                      // |logit q| range the slim stage takes (rvll_set_slim_table_range; default: the table's)
+    int* pin_defer = nullptr;                   // mapped pinned word the slim stage sets when it defers an element
+    int* pin_defer_dev = nullptr;
+    long long fused_pending = 0;                // rows of a one-launch cube -> log-L batch whose defer word has not been looked at yet
 
     // batch buffers
     long long cap = 0;
@@ -193,6 +198,7 @@ struct rvll_handle {
     double *d_walk_u = nullptr, *d_walk_theta = nullptr, *d_walk_logl = nullptr, *d_walk_chol = nullptr;
     int32_t* d_walk_wrapped = nullptr;
     unsigned long long* d_walk_ncalls = nullptr;
+    int32_t *d_walk_steps = nullptr, *d_walk_wid = nullptr, *d_walk_start = nullptr;   // [walk_cap] each
 
     hipEvent_t marks[2] = {nullptr, nullptr};   // rvll_dev_mark: HIP events on lane 0's stream
 
@@ -240,11 +246,15 @@ int server_stop(rvll_handle* h)
     return RVLL_OK;
 }
 
+int resolve_fused(rvll_handle* h);
+
 int use_device(rvll_handle* h)
 {
     if (!h) return fail(RVLL_E_INVALID, "null handle");
     HIP_TRY(hipSetDevice(h->device));
-    return server_stop(h);
+    int rc = server_stop(h);
+    if (rc) return rc;
+    return h->fused_pending ? resolve_fused(h) : RVLL_OK;
 }
 
 bool slot_ok(const rvll_slot& s, int D) { return s.idx < D; }
@@ -345,15 +355,22 @@ int choose_points_per_block(rvll_handle* h, long long B)
 }
 
 // The CU-wide form (rvll_kernels.hip, loglike_cu_kernel): 1024-thread workgroups, one per CU at a time, each taking
-// a tile of PB points whose items all sit in LDS.  Chosen when every CU gets enough wave rounds to keep its 16 waves
-// busy (below that the 256-thread tiles pack small batches better) and one point's items fit the LDS budget.  The
-// tile size is the largest that fits, lowered so that the number of tiles is a whole number of rounds over the CUs.
+// a tile of PB points whose items all sit in LDS.  Measured against the 256-thread tiles over batch sizes
+// (profiles/r02_form_sweep.txt): 7-14 % faster whenever the batch is one to four rounds of tiles over the CUs —
+// every CU stays full until its last wave round — down to a few wave rounds per CU; with many rounds per CU the
+// tile form wins by 2-7 %, because a CU-filling workgroup's prologue and reduction (~5 us per tile) overlap
+// nothing, while four independent workgroups per CU hide each other's.  The tile size is the largest that fits
+// the LDS budget, lowered so that the number of tiles is a whole number of rounds over the CUs.
 // Returns the grid (0: use the tile form) and sets a->PB / a->CH.
 int choose_cu_form(rvll_handle* h, long long B, rvll::LoglikeArgs* a)
 {
     if (h->form_override == 1 || h->pb_override > 0) return 0;
+    const bool forced = h->form_override == 2;
+    // two launches in flight (pipeline lanes): the next launch's tiles backfill every freed slot, which is all the
+    // CU-wide form buys, and the 256-thread tiles hide their prologues behind each other (2.71 vs 2.59e8 evals/s)
+    if (h->pipelined && !forced) return 0;
     const long long wave_rounds_per_cu = B * h->Ne / rvll::kWave / std::max(1, h->n_cu);
-    if (h->form_override != 2 && wave_rounds_per_cu < 96) return 0;
+    if (!forced && wave_rounds_per_cu < 8) return 0;
     const long long ncu = std::min<long long>(h->n_cu, B);
     const long long ppc = (B + ncu - 1) / ncu;                      // points per CU
     rvll::LoglikeArgs t = *a;
@@ -365,6 +382,7 @@ int choose_cu_form(rvll_handle* h, long long B, rvll::LoglikeArgs* a)
     while (pbmax >= 1 && !fits(pbmax)) --pbmax;
     if (pbmax < 1) return 0;
     const long long rounds = (ppc + pbmax - 1) / pbmax;             // tiles per CU
+    if (!forced && rounds > 4) return 0;
     const int pb = (int)((B + ncu * rounds - 1) / (ncu * rounds));
     a->PB = pb;
     a->CH = (pb * h->Ne + 1) & ~1;
@@ -418,6 +436,8 @@ void make_fused(const rvll_handle* h, const double* d_cube, double* d_theta_out,
     a->priors = h->d_priors;
     a->heavy_dims = h->d_heavy;
     a->n_heavy = h->n_heavy;
+    a->defer = h->pin_defer_dev;
+    a->slim_umax = h->slim_umax;
 }
 
 int ensure_capacity(rvll_handle* h, long long B)
@@ -449,6 +469,7 @@ void free_priors(rvll_handle* h)
     dev_free(h->d_priors);
     dev_free(h->d_heavy);
     h->n_heavy = 0;
+    h->all_direct = true;
     h->have_priors = false;
 }
 
@@ -545,6 +566,15 @@ int rvll_create(const rvll_layout* layout, const double* time, const double* vra
     CREATE_TRY(hipHostGetDevicePointer(&h->pin_in_dev, h->pin_in, 0));
     CREATE_TRY(hipHostGetDevicePointer(&h->pin_out_dev, h->pin_out, 0));
     {
+        void *p = nullptr, *pd = nullptr;
+        CREATE_TRY(hipHostMalloc(&p, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        CREATE_TRY(hipHostGetDevicePointer(&pd, p, 0));
+        h->pin_defer = static_cast<int*>(p);
+        h->pin_defer_dev = static_cast<int*>(pd);
+        *h->pin_defer = 0;
+        h->slim_umax = rvll::prior_table_umax();
+    }
+    {
         void* p = nullptr;
         CREATE_TRY(hipHostMalloc(&p, sizeof(rvll::ServerCtl), hipHostMallocMapped | hipHostMallocCoherent));
         h->srv = new (p) rvll::ServerCtl();
@@ -610,6 +640,8 @@ int rvll_destroy(rvll_handle* h)
     dev_free(h->d_gather_theta);
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
+    if (h->pin_defer) (void)hipHostFree(h->pin_defer);
+    dev_free(h->d_walk_steps); dev_free(h->d_walk_wid); dev_free(h->d_walk_start);
     for (auto& e : h->marks) if (e) (void)hipEventDestroy(e);
     if (h->srv_stream) (void)hipStreamDestroy(h->srv_stream);
     if (h->srv) (void)hipHostFree(h->srv);
@@ -715,6 +747,8 @@ int rvll_set_priors(rvll_handle* h, const rvll_prior* priors, int32_t ndim)
         HIP_TRY(hipMemcpy(h->d_heavy, heavy.data(), sizeof(int32_t) * heavy.size(), hipMemcpyHostToDevice));
     }
     h->n_heavy = (int)heavy.size();
+    h->all_direct = true;
+    for (int32_t d : heavy) if (!h->table_direct[(size_t)d]) h->all_direct = false;
     HIP_TRY(hipStreamSynchronize(h->compute));          // start tables are built
     h->have_priors = true;
     return RVLL_OK;
@@ -831,15 +865,26 @@ int rvll_dev_prior_loglike(rvll_handle* h, int64_t B)
     if (!h->have_priors) return fail(RVLL_E_NOPRIORS, "rvll_set_priors has not been called");
     if (B < 0 || B > h->cap) return fail(RVLL_E_INVALID, "B %lld outside reserved capacity %lld", (long long)B, h->cap);
     if (B == 0) return RVLL_OK;
+    // One launch (the prior transform in the log-L tile's staging step) pays for small batches, where a launch is a
+    // large part of the step, and needs every Beta / Gamma prior to have a verified table (the slim stage).  Otherwise:
+    // the prior kernels, then the log-L kernel in whichever form the batch size selects.
+    if (B > kFusedMaxPoints || !h->all_direct || h->form_override == 2) {
+        rc = rvll_dev_prior(h, B);
+        if (rc) return rc;
+        if (h->logl_cur != 0) h->logl_cur = 0;     // results of this call live on lane 0, as the one-launch form's do
+        return rvll_dev_loglike(h, B);
+    }
     rc = sync_other_lanes(h);                  // theta is rewritten: no other lane may still be reading it
     if (rc) return rc;
     rvll::LoglikeArgs a;
     rc = build_args(h, h->d_theta, h->d_logL2[0], h->d_flags2[0], B, &a);
     if (rc) return rc;
     make_fused(h, h->d_cube, h->d_theta, &a);
+    *h->pin_defer = 0;                         // no slim launch is in flight here: use_device resolved the last one
     HIP_TRY(rvll::launch_prior_loglike(a, h->compute));
     h->theta_async = true;
     h->logl_last = 0;
+    h->fused_pending = B;                      // whoever touches the results next looks at the defer word first
     return RVLL_OK;
 }
 
@@ -1008,6 +1053,22 @@ int rvll_dev_trace_loglike(rvll_handle* h, int64_t B, int32_t warmup, uint64_t* 
 
 namespace {
 
+// A one-launch cube -> log-L batch is in flight or finished: wait for it and, if its slim prior stage deferred any
+// element (a quantile outside its table: |logit q| > 30, q = 0 or 1, ...), redo the batch with the prior kernels
+// that carry the full solvers — the same rows, the same buffers, bit-identical results for every other point.
+int resolve_fused(rvll_handle* h)
+{
+    const long long B = h->fused_pending;
+    h->fused_pending = 0;
+    HIP_TRY(hipStreamSynchronize(h->compute));
+    if (__atomic_load_n(h->pin_defer, __ATOMIC_ACQUIRE) == 0) return RVLL_OK;
+    *h->pin_defer = 0;
+    int rc = rvll_dev_prior(h, B);
+    if (rc) return rc;
+    h->logl_cur = 0;
+    return rvll_dev_loglike(h, B);
+}
+
 int server_start(rvll_handle* h)
 {
     HIP_TRY(hipSetDevice(h->device));
@@ -1173,7 +1234,7 @@ int rvll_prior_loglike_batch(rvll_handle* h, const double* cube, int64_t B,
     if (!cube || !logL) return fail(RVLL_E_INVALID, "cube/logL is null");
     const size_t nin = sizeof(double) * (size_t)B * (size_t)h->L.ndim;
     const size_t nout = (sizeof(double) + sizeof(int32_t)) * (size_t)B;
-    if (nin <= 64 * 1024 && nout <= 64 * 1024) {
+    if (nin <= 64 * 1024 && nout <= 64 * 1024 && h->all_direct) {
         // small batch (a sampler's proposal round): the fused kernel reads the cube from mapped pinned host
         // memory, theta goes to HBM, log-L and flags are written back zero-copy; theta returns with one copy
         // command into the same pinned block
@@ -1189,10 +1250,23 @@ int rvll_prior_loglike_batch(rvll_handle* h, const double* cube, int64_t B,
         rc = build_args(h, h->d_theta, out_l, out_f, B, &a);
         if (rc) return rc;
         make_fused(h, static_cast<const double*>(h->pin_in_dev), h->d_theta, &a);
+        *h->pin_defer = 0;
         HIP_TRY(rvll::launch_prior_loglike(a, h->compute));
         char* host_out = static_cast<char*>(h->pin_out);
         if (theta_out) HIP_TRY(hipMemcpyAsync(host_out + nout, h->d_theta, nin, hipMemcpyDeviceToHost, h->compute));
         HIP_TRY(hipStreamSynchronize(h->compute));
+        if (__atomic_load_n(h->pin_defer, __ATOMIC_ACQUIRE) != 0) {
+            // an element fell outside the slim stage's tables (rvll_tile.h): the full prior kernels take the batch
+            *h->pin_defer = 0;
+            rc = rvll_dev_upload_cube(h, cube, B);
+            if (rc) return rc;
+            rc = rvll_dev_prior(h, B);
+            if (rc) return rc;
+            h->logl_cur = 0;
+            rc = rvll_dev_loglike(h, B);
+            if (rc) return rc;
+            return rvll_dev_download(h, B, theta_out, logL, flags);
+        }
         memcpy(logL, host_out, sizeof(double) * (size_t)B);
         if (flags) memcpy(flags, host_out + sizeof(double) * (size_t)B, sizeof(int32_t) * (size_t)B);
         if (theta_out) memcpy(theta_out, host_out + nout, nin);
@@ -1249,15 +1323,8 @@ int rvll_prior_loglike_batch(rvll_handle* h, const double* cube, int64_t B,
     // measured (profiles/r01_fused_probe.txt): one launch saves ~1 us up to a few thousand points; beyond that
     // the separate prior kernels win by ~5 % because their work spreads over the whole chip instead of
     // running as a short serial prologue of every log-L workgroup
-    if (B <= kFusedMaxPoints) {
-        rc = rvll_dev_prior_loglike(h, B);
-        if (rc) return rc;
-    } else {
-        rc = rvll_dev_prior(h, B);
-        if (rc) return rc;
-        rc = rvll_dev_loglike(h, B);
-        if (rc) return rc;
-    }
+    rc = rvll_dev_prior_loglike(h, B);
+    if (rc) return rc;
     return rvll_dev_download(h, B, theta_out, logL, flags);
 }
 
@@ -1284,11 +1351,15 @@ int rvll_slice_walk(rvll_handle* h, double* cube, double* theta, double* logl, i
     if (K > h->walk_cap || !h->d_walk_chol) {
         HIP_TRY(hipStreamSynchronize(h->compute));
         dev_free(h->d_walk_u); dev_free(h->d_walk_theta); dev_free(h->d_walk_logl);
+        dev_free(h->d_walk_steps); dev_free(h->d_walk_wid); dev_free(h->d_walk_start);
         h->walk_cap = 0;
         const size_t cap = (size_t)std::max<long long>(K, 1024);
         HIP_TRY(hipMalloc(&h->d_walk_u, sizeof(double) * D * cap));
         HIP_TRY(hipMalloc(&h->d_walk_theta, sizeof(double) * D * cap));
         HIP_TRY(hipMalloc(&h->d_walk_logl, sizeof(double) * cap));
+        HIP_TRY(hipMalloc(&h->d_walk_steps, sizeof(int32_t) * cap));
+        HIP_TRY(hipMalloc(&h->d_walk_wid, sizeof(int32_t) * cap));
+        HIP_TRY(hipMalloc(&h->d_walk_start, sizeof(int32_t) * cap));
         if (!h->d_walk_chol) {
             HIP_TRY(hipMalloc(&h->d_walk_chol, sizeof(double) * D * D));
             HIP_TRY(hipMalloc(&h->d_walk_wrapped, sizeof(int32_t) * D));
@@ -1307,29 +1378,91 @@ int rvll_slice_walk(rvll_handle* h, double* cube, double* theta, double* logl, i
     HIP_TRY(hipMemsetAsync(h->d_walk_ncalls, 0, sizeof(unsigned long long), st));
     HIP_TRY(hipStreamSynchronize(st));                 // wr (and pageable sources) may go out of scope
 
-    rvll::LoglikeArgs a;
-    rc = build_args(h, h->d_theta, h->d_logL2[0], h->d_flags2[0], K, &a);
-    if (rc) return rc;
-    make_fused(h, h->d_cube, h->d_theta, &a);
     // the walk keeps per-walker state in LDS next to the tile's carve: shrink the group until both fit
-    while (a.PB > 1 && (rvll::walk_lds_bytes(a) > 60 * 1024 || (long long)a.PB * a.D > 4 * rvll::kThreads)) {
-        a.PB -= 1;
-        a.CH = std::min(h->chunk_items, std::max(rvll::kThreads, a.PB * h->Ne));
-        a.CH = (a.CH + 1) & ~1;
-    }
-    if (rvll::walk_lds_bytes(a) > 64 * 1024 || (long long)a.PB * a.D > 4 * rvll::kThreads)
-        return fail(RVLL_E_UNSUPPORTED, "%d parameters exceed the walk kernel's LDS budget", a.D);
+    auto walk_args = [&](long long n, rvll::LoglikeArgs* a) -> int {
+        int r = build_args(h, h->d_theta, h->d_logL2[0], h->d_flags2[0], n, a);
+        if (r) return r;
+        make_fused(h, h->d_cube, h->d_theta, a);
+        a->defer = nullptr;                            // deferrals are per walker here (steps_done), not per batch
+        while (a->PB > 1 && (rvll::walk_lds_bytes(*a) > 60 * 1024 || (long long)a->PB * a->D > 4 * rvll::kThreads)) {
+            a->PB -= 1;
+            a->CH = std::min(h->chunk_items, std::max(rvll::kThreads, a->PB * h->Ne));
+            a->CH = (a->CH + 1) & ~1;
+        }
+        if (rvll::walk_lds_bytes(*a) > 64 * 1024 || (long long)a->PB * a->D > 4 * rvll::kThreads)
+            return fail(RVLL_E_UNSUPPORTED, "%d parameters exceed the walk kernel's LDS budget", a->D);
+        return RVLL_OK;
+    };
+    rvll::LoglikeArgs a;
+    rc = walk_args(K, &a);
+    if (rc) return rc;
+    // Slim walk (verified-table quantiles only, 4 waves per SIMD) when every Beta / Gamma prior has such a table;
+    // walkers it could not finish come back with steps_done < nsteps and are finished by the fat kernel below.
+    const bool slim = h->all_direct && !getenv("RVLL_WALK_FAT");
     rvll::WalkArgs w{h->d_walk_u, h->d_walk_theta, h->d_walk_logl, h->d_walk_chol, h->d_walk_wrapped, (long long)K,
-                     nsteps, max_rounds, (unsigned long long)seed, lstar, h->d_walk_ncalls};
-    HIP_TRY(rvll::launch_slice_walk(a, w, st));
+                     nsteps, max_rounds, (unsigned long long)seed, lstar, h->d_walk_ncalls,
+                     h->d_walk_steps, nullptr, nullptr};
+    HIP_TRY(rvll::launch_slice_walk(a, w, !slim, st));
     unsigned long long n = 0;
+    std::vector<int32_t> steps(slim ? (size_t)K : 0);
     HIP_TRY(hipMemcpyAsync(cube, h->d_walk_u, sizeof(double) * D * (size_t)K, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(theta, h->d_walk_theta, sizeof(double) * D * (size_t)K, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(logl, h->d_walk_logl, sizeof(double) * (size_t)K, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&n, h->d_walk_ncalls, sizeof n, hipMemcpyDeviceToHost, st));
+    if (slim) HIP_TRY(hipMemcpyAsync(steps.data(), h->d_walk_steps, sizeof(int32_t) * (size_t)K, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    if (ncalls) *ncalls = (int64_t)n;
+    unsigned long long total = n;
+    if (slim) {
+        std::vector<int32_t> ids, start;
+        for (int64_t i = 0; i < K; ++i)
+            if (steps[(size_t)i] < nsteps) { ids.push_back((int32_t)i); start.push_back(steps[(size_t)i]); }
+        if (!ids.empty()) {
+            // finish the interrupted walkers with the full solvers inline: same seed, same walker index in the
+            // random-number counters, resumed at the start of the move that was interrupted
+            const size_t M = ids.size();
+            std::vector<double> su(M * D), sth(M * D), sl(M);
+            for (size_t j = 0; j < M; ++j) {
+                memcpy(&su[j * D], cube + (size_t)ids[j] * D, sizeof(double) * D);
+                memcpy(&sth[j * D], theta + (size_t)ids[j] * D, sizeof(double) * D);
+                sl[j] = logl[ids[j]];
+            }
+            HIP_TRY(hipMemcpyAsync(h->d_walk_u, su.data(), sizeof(double) * D * M, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(h->d_walk_theta, sth.data(), sizeof(double) * D * M, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(h->d_walk_logl, sl.data(), sizeof(double) * M, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(h->d_walk_wid, ids.data(), sizeof(int32_t) * M, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(h->d_walk_start, start.data(), sizeof(int32_t) * M, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemsetAsync(h->d_walk_ncalls, 0, sizeof(unsigned long long), st));
+            rvll::LoglikeArgs a2;
+            rc = walk_args((long long)M, &a2);
+            if (rc) return rc;
+            rvll::WalkArgs w2 = w;
+            w2.K = (long long)M;
+            w2.walker_id = h->d_walk_wid;
+            w2.step_start = h->d_walk_start;
+            HIP_TRY(rvll::launch_slice_walk(a2, w2, true, st));
+            HIP_TRY(hipMemcpyAsync(su.data(), h->d_walk_u, sizeof(double) * D * M, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(sth.data(), h->d_walk_theta, sizeof(double) * D * M, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(sl.data(), h->d_walk_logl, sizeof(double) * M, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(&n, h->d_walk_ncalls, sizeof n, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            total += n;
+            for (size_t j = 0; j < M; ++j) {
+                memcpy(cube + (size_t)ids[j] * D, &su[j * D], sizeof(double) * D);
+                memcpy(theta + (size_t)ids[j] * D, &sth[j * D], sizeof(double) * D);
+                logl[ids[j]] = sl[j];
+            }
+        }
+    }
+    if (ncalls) *ncalls = (int64_t)total;
     h->theta_async = false;
+    return RVLL_OK;
+}
+
+int rvll_set_slim_table_range(rvll_handle* h, double umax)
+{
+    if (!h) return fail(RVLL_E_INVALID, "null handle");
+    if (!(umax >= 0.)) return fail(RVLL_E_INVALID, "umax must be >= 0");
+    h->slim_umax = std::min(umax, rvll::prior_table_umax());
     return RVLL_OK;
 }
 

@@ -50,6 +50,11 @@ struct LoglikeArgs {
     const rvll_prior*  priors;      // [D]
     const int32_t*     heavy_dims;  // [n_heavy] parameters with an iterative quantile (Beta, Gamma)
     int                n_heavy;
+    // slim form of that stage (kFusedSlim): Beta / Gamma quantiles are evaluated by the verified table alone; an
+    // element it cannot take (|logit q| > slim_umax, q on the boundary) marks its point kFlagDeferred, sets *defer
+    // (may be null) and yields NaN — the host redoes such points through the kernels that carry the full solvers
+    int*               defer;
+    double             slim_umax;
     // diagnostic build only (launch_loglike_trace): kTraceWords stamps per workgroup, nullptr otherwise
     unsigned long long* trace;
 };
@@ -65,6 +70,9 @@ hipError_t launch_loglike_trace(const LoglikeArgs& a, hipStream_t stream);
 hipError_t launch_loglike_cu(const LoglikeArgs& a, int grid, hipStream_t stream);
 
 size_t loglike_lds_bytes(const LoglikeArgs& a);
+// prior transform inside the tile's staging step: none / verified tables only / with the full solvers inline
+constexpr int kFusedNone = 0, kFusedSlim = 1, kFusedFull = 2;
+constexpr int kFlagDeferred = 0x40000000;     // internal flag bit, never returned to the caller
 
 // ---- device-resident slice-sampling walk (the proposal step of nested sampling; evidence_amd/nested.py) -------
 // K walkers start at cube points u (log-L above lstar) and take nsteps hit-and-run slice moves inside the region
@@ -83,10 +91,16 @@ struct WalkArgs {
     unsigned long long seed;
     double lstar;
     unsigned long long* ncalls;   // += likelihood evaluations
+    int32_t* steps_done;       // [K] out: moves completed (< nsteps: the walker met a candidate the slim prior stage
+                               //          deferred and stopped at the start of that move)
+    const int32_t* walker_id;  // [K] or null: the walker's index in the random-number counters (default: its row)
+    const int32_t* step_start; // [K] or null: move to resume at (default 0)
 };
 size_t walk_lds_bytes(const LoglikeArgs& a);
 // a: fused (cube -> theta -> log-L) arguments whose cube / theta_out / logL / flags rows [0, K) are scratch
-hipError_t launch_slice_walk(const LoglikeArgs& a, const WalkArgs& w, hipStream_t stream);
+// fat = false: slim prior stage (4 waves per SIMD; deferring walkers report steps_done < nsteps);
+// fat = true : full solvers inline (every walker finishes)
+hipError_t launch_slice_walk(const LoglikeArgs& a, const WalkArgs& w, bool fat, hipStream_t stream);
 
 // ---- scalar-call server: a one-workgroup persistent kernel that answers single-point log-L requests through a
 // block of host-coherent pinned memory, so a scalar callback costs a PCIe round trip instead of a kernel launch
@@ -129,6 +143,7 @@ hipError_t launch_prior_loglike(const LoglikeArgs& a, hipStream_t stream);
 // n = prior_table_nodes(); if max_err_bits (a zeroed device word) is given, the quintic interpolant's error
 // against the full solver is measured into it (bits of a double; compare with prior_table_direct_tol())
 int prior_table_nodes();
+double prior_table_umax();     // |logit q| the tables cover
 double prior_table_direct_tol();
 hipError_t launch_prior_table(int kind, const double* args, double* z, double* dz, unsigned long long* max_err_bits,
                               hipStream_t stream);

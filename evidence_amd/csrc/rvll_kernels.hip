@@ -17,630 +17,11 @@
 // Roofline: this path is fp64-VALU bound (software sin/cos, IEEE division); HBM
 // traffic is theta in + log-L out (+ the epoch table, L2-resident).  No MFMA: there
 // is no contraction here.
-#include "rvll_kernels.h"
-#include "rvll_math.h"
-#include "rvll_special.h"
+#include "rvll_tile.h"
 
 namespace rvll {
 
 namespace {
-
-constexpr double kTwoPi = 6.283185307179586476925286766559;   // fl(2*pi), as 2*np.pi
-
-__device__ __forceinline__ double slot_get(const rvll_slot s, const double* th)
-{
-    return s.idx >= 0 ? th[s.idx] : s.val;
-}
-
-// the same for a slot staged in LDS: both candidates are read, no dependent branch
-__device__ __forceinline__ double slot_lds(const rvll_slot* s, const double* th)
-{
-    const int idx = s->idx;
-    const double v = s->val;
-    const double tv = th[idx >= 0 ? idx : 0];
-    return idx >= 0 ? tv : v;
-}
-
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-
-// The value `off` lanes further up, for the lanes a wave_sum tree still needs at that step (lane < off), without
-// the LDS crossbar: v_permlane32_swap / v_permlane16_swap (gfx950) exchange the upper half of one register with the
-// lower half of another (32- or 16-lane halves), row_shl DPP shifts within a 16-lane row.  ~10 cycles per step
-// instead of ~120 for a ds_bpermute pair — the reduction of a tile is a serial tail nothing else overlaps.
-__device__ __forceinline__ double lanes_up_32(double v)
-{
-    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-    const auto a = __builtin_amdgcn_permlane32_swap((unsigned)u, (unsigned)u, false, false);
-    const auto b = __builtin_amdgcn_permlane32_swap((unsigned)(u >> 32), (unsigned)(u >> 32), false, false);
-    return __builtin_bit_cast(double, ((unsigned long long)b[1] << 32) | a[1]);
-}
-__device__ __forceinline__ double lanes_up_16(double v)
-{
-    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-    const auto a = __builtin_amdgcn_permlane16_swap((unsigned)u, (unsigned)u, false, false);
-    const auto b = __builtin_amdgcn_permlane16_swap((unsigned)(u >> 32), (unsigned)(u >> 32), false, false);
-    return __builtin_bit_cast(double, ((unsigned long long)b[1] << 32) | a[1]);
-}
-template <int N>
-__device__ __forceinline__ double lanes_up_row(double v)
-{
-    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
-    const int l = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, 0x100 + N, 0xf, 0xf, true);          // row_shl:N
-    const int h = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), 0x100 + N, 0xf, 0xf, true);
-    return __builtin_bit_cast(double, ((unsigned long long)(unsigned)h << 32) | (unsigned)l);
-}
-// wave_sum's tree, valid in LANE 0 only (the other lanes hold partial garbage): same additions, same order
-__device__ __forceinline__ double wave_sum_lane0(double v)
-{
-    v += lanes_up_32(v);
-    v += lanes_up_16(v);
-    v += lanes_up_row<8>(v);
-    v += lanes_up_row<4>(v);
-    v += lanes_up_row<2>(v);
-    v += lanes_up_row<1>(v);
-    return v;
-}
-
-// LDS carve-up, all in units of doubles except the int tail.
-constexpr int kPlanetDoubles = (int)(sizeof(rvll_planet) / sizeof(double));
-constexpr int kInstDoubles   = (int)(sizeof(rvll_inst) / sizeof(double));
-constexpr int kSlotDoubles   = (int)(sizeof(rvll_slot) / sizeof(double));
-static_assert(sizeof(rvll_planet) % 8 == 0 && sizeof(rvll_inst) % 8 == 0 && sizeof(rvll_slot) == 16, "layout structs are copied as doubles");
-struct Carve {
-    int theta, pp, ins, dr, lin, acc, lay, contrib, ints, total_doubles;
-};
-__host__ __device__ inline int layout_doubles(int Np, int Ni, int nlin)
-{
-    return Np * kPlanetDoubles + Ni * kInstDoubles + (nlin + 5) * kSlotDoubles;   // + the four drift slots and tref
-}
-__host__ __device__ inline Carve carve(int PB, int D, int Np, int Ni, int nlin, int CH)
-{
-    Carve c;
-    int o = 0;
-    c.theta = o;   o += PB * D;
-    o = (o + 1) & ~1;                       // 16-byte align the double2-read regions
-    c.pp = o;      o += PB * Np * kPlanetFields;
-    c.ins = o;     o += PB * Ni * 2;
-    c.dr = o;      o += PB * 6;
-    c.lin = o;     o += PB * nlin;
-    c.acc = o;     o += PB;
-    c.lay = o;     o += layout_doubles(Np, Ni, nlin);   // the layout structs, staged once per workgroup
-    o = (o + 1) & ~1;
-    c.contrib = o; o += CH;
-    c.ints = o;    // ints: nfail[1] ticket[1] pflags[PB] anyfail[PB] jfail[PB*Np]
-    const int nints = 2 + 2 * PB + PB * Np;
-    o += (nints + 1) / 2;
-    c.total_doubles = o;
-    return c;
-}
-
-// ---------------------------------------------------------------------------
-// prior transform (device functions shared by the prior kernels and the fused cube -> log-L kernel)
-// ---------------------------------------------------------------------------
-
-// Piecewise-linear inverse CDF on a host-built grid; the semantics of
-// scipy.interpolate.interp1d(cdf, x)(q) (which evaluates 1-D linear tables through
-// numpy.interp) as used by priors.py:118-124 and friends.
-__device__ double table_ppf(const rvll_prior& pr, double q)
-{
-    const int n = pr.table_n;
-    const double* xp = pr.table_cdf;
-    const double* fp = pr.table_x;
-    const bool wrapped = pr.args[2] != 0.;
-    if (wrapped) {                       // scipy rv_continuous.ppf front end
-        if (q == 0.) return pr.args[0];
-        if (q == 1.) return pr.args[1];
-        if (!(q > 0. && q < 1.)) return NAN;
-    }
-    if (!(q >= xp[0] && q <= xp[n - 1])) return NAN;   // interp1d raises ValueError here
-    // last j with xp[j] <= q
-    int lo = 0, hi = n;                  // invariant: xp[lo] <= q, (hi == n or xp[hi] > q)
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (xp[mid] <= q) lo = mid; else hi = mid;
-    }
-    const int j = lo;
-    double y;
-    if (j == n - 1) y = fp[j];
-    else if (xp[j] == q) y = fp[j];
-    else {
-        const double slope = (fp[j + 1] - fp[j]) / (xp[j + 1] - xp[j]);
-        y = slope * (q - xp[j]) + fp[j];
-        if (isnan(y)) {
-            y = slope * (q - xp[j + 1]) + fp[j + 1];
-            if (isnan(y) && fp[j] == fp[j + 1]) y = fp[j];
-        }
-    }
-    return pr.table_post ? pow(10., y) : y;
-}
-
-// Forced-identifiability transform of pypolychord's SortedUniformPrior / LogSortedUniformPrior
-// (evidence/priors.py:462-467, grouped call in evidence/polychord/__init__.py:145-160):
-//   t[N-1] = x[N-1]^(1/N),  t[n] = x[n]^(1/(n+1)) t[n+1]   over the group's members in
-// parameter order, then a + (b-a) t  (or a (b/a)^t).  Every member of kind `kind` belongs to
-// the one group, and the bounds of the LAST member are used, as the wrapper does.
-__device__ double sorted_prior(const rvll_prior* priors, int D, const double* cube_row, int d, int kind)
-{
-    int rank = 0, last = d;
-    for (int k = 0; k < D; ++k)
-        if (priors[k].kind == kind) { if (k < d) ++rank; last = k; }
-    double t = 1.;
-    int n = rank;
-    for (int k = d; k < D; ++k)
-        if (priors[k].kind == kind) { t *= pow(cube_row[k], 1.0 / (double)(n + 1)); ++n; }
-    const double lo = priors[last].args[0], hi = priors[last].args[1];
-    return kind == RVLL_PRIOR_SORTED_UNIFORM ? lo + (hi - lo) * t : lo * pow(hi / lo, t);
-}
-
-__device__ __forceinline__ bool prior_is_heavy(int kind) { return kind == RVLL_PRIOR_BETA || kind == RVLL_PRIOR_GAMMA; }
-
-// Light kinds: a handful of instructions (or one table search) for parameter d of one cube row.
-__device__ double prior_light(const rvll_prior* priors, int D, const double* cube_row, int d)
-{
-    const rvll_prior& pr = priors[d];
-    const double q = cube_row[d];
-    switch (pr.kind) {
-    case RVLL_PRIOR_UNIFORM:             // priors.py:41-42
-        return pr.args[0] + (pr.args[1] - pr.args[0]) * q;
-    case RVLL_PRIOR_JEFFREYS:            // priors.py:62-63
-        return pr.args[0] * pow(pr.args[1] / pr.args[0], q);
-    case RVLL_PRIOR_MODJEFFREYS:         // priors.py:82-83
-        return pr.args[0] * pow(1 + pr.args[1] / pr.args[0], q) - pr.args[0];
-    case RVLL_PRIOR_UNIFORMFREQUENCY:    // priors.py:100-101
-        return pr.args[0] / (1 - q * (pr.args[1] - pr.args[0]) / pr.args[1]);
-    case RVLL_PRIOR_NORMAL:              // stats.norm.ppf: loc + scale*ndtri(q)
-        return (q >= 0. && q <= 1.) ? ndtri_f64(q) * pr.args[1] + pr.args[0] : NAN;
-    case RVLL_PRIOR_LOGNORMAL:           // stats.lognorm.ppf: loc + scale*exp(s*ndtri(q))
-        return (q >= 0. && q <= 1.) ? exp(pr.args[0] * ndtri_f64(q)) * pr.args[2] + pr.args[1] : NAN;
-    case RVLL_PRIOR_TRUNCRAYLEIGH: {     // priors.py:249-252
-        const double sg = pr.args[0], xm = pr.args[1];
-        const double A = 1 - exp(-(xm * xm) / (2 * (sg * sg)));
-        return sqrt(-2 * (sg * sg) * log(1 - (q * A))); }
-    case RVLL_PRIOR_TABLE:
-        return table_ppf(pr, q);
-    case RVLL_PRIOR_ALPHA:               // stats.alpha.ppf(q, a); args[1] = Phi(a)
-        return alpha_ppf(q, pr.args[0], pr.args[1]);
-    case RVLL_PRIOR_SORTED_UNIFORM:
-    case RVLL_PRIOR_SORTED_LOGUNIFORM:
-        return sorted_prior(priors, D, cube_row, d, pr.kind);
-    default:
-        return NAN;
-    }
-}
-
-// Iterative quantiles (bracketed Newton on the regularised incomplete beta / gamma) from the device-built
-// start table (table_cdf / table_x hold z and dz/du of this prior, or null).
-__device__ double prior_heavy(const rvll_prior& pr, double q)
-{
-    const bool direct = pr.table_post != 0;   // rvll_set_priors verified the quintic interpolant of this prior
-    if (pr.kind == RVLL_PRIOR_BETA)      // stats.beta.ppf(q, a, b); args[2] = ln B(a,b)
-        return beta_ppf_table(q, pr.args[0], pr.args[1], pr.args[2], pr.table_cdf, pr.table_x, direct);
-    // stats.gamma.ppf(q, alpha, scale=1/beta); args[2] = ln Gamma(alpha)
-    return gamma_ppf_table(q, pr.args[0], pr.args[1], pr.args[2], pr.table_cdf, pr.table_x, direct);
-}
-
-// Per-block LDS views handed to eval_item (plain pointers; the kernel arguments
-// themselves are passed by reference so they stay in the scalar kernarg segment).
-struct ItemCtx {
-    const double* pp;
-    const double* ins;
-    const double* dr;
-    const double* lin;
-    int* nfail;
-    int* anyfail;
-    int* jfail;
-};
-
-// One (point, epoch) item: returns ln sqrt(var) + res^2 / (2 var).
-template <int PREC>
-__device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx& cx, int pl, int j)
-{
-    const double t  = a.t[j];
-    const double y  = a.y[j];
-    const double s2 = a.s2[j];
-    const int    in = a.inst[j];
-
-    const double2 oj = *reinterpret_cast<const double2*>(cx.ins + (pl * a.Ni + in) * 2);
-    double rvm = 0. + oj.x;                                   // rvmodel:187
-    const double var = s2 + oj.y;                             // rvmodel:189-192 (oj.y = jitter^2 or 0)
-
-    if (a.Np > 0) {
-        const bool point_failed = cx.anyfail[pl] != 0;
-        double ksum = 0.;
-        for (int ip = 0; ip < a.Np; ++ip) {
-            const double* P = cx.pp + (pl * a.Np + ip) * kPlanetFields;
-            const double2 p01 = *reinterpret_cast<const double2*>(P);       // w, epoch
-            const double2 p23 = *reinterpret_cast<const double2*>(P + 2);   // ma0, ec
-            const double2 p45 = *reinterpret_cast<const double2*>(P + 4);   // A=K cos w, Bq=K q sin w
-            const double  C0  = P[6];                                       // K e cos w
-            const double ec = p23.y;
-            double rv;
-            if (point_failed && j >= cx.jfail[pl * a.Np + ip]) {
-                rv = p45.x + C0;            // nu left at 0 (rvmodel:488, trueanomaly.c:32-33)
-            } else if constexpr (PREC == RVLL_PREC_FP64) {
-                // mean anomaly, rvmodel:459 — two roundings in (t-epoch), then mul, then add
-                const double M = p01.x * (t - p01.y) + p23.x;
-                // Newton, trueanomaly.c:17-33 — op-by-op, no contraction
-                double E = M, s, c, dE;
-                int steps = 0;
-                do {
-                    sincos_f64(E, s, c);
-                    const double f  = E - ec * s - M;
-                    const double fp = 1 - ec * c;
-                    const double En = E - div_exact(f, fp);            // == f / fp, correctly rounded
-                    dE = En - E;
-                    E = En;
-                    ++steps;
-                } while (fabs(dE) > a.tol && steps < a.itmax);
-                if (steps >= a.itmax) {
-                    atomicMin(&cx.jfail[pl * a.Np + ip], j);
-                    atomicOr(&cx.anyfail[pl], 1);
-                    atomicOr(cx.nfail, 1);
-                    rv = p45.x + C0;
-                } else {
-                    // (s, c) are at the previous iterate; the accepted step |dE| <= tol:
-                    // rotate instead of a third range reduction.
-                    if (a.tol <= 1e-3) rotate_small(dE, s, c);
-                    else               sincos_f64(E, s, c);
-                    // K (cos(nu+w) + e cos w) with cos nu = (cos E - e)/(1 - e cos E),
-                    // sin nu = sqrt(1-e^2) sin E/(1 - e cos E)  == trueanomaly.c:36 + rvmodel:463
-                    const double den = __builtin_fma(-ec, c, 1.0);
-                    const double num = __builtin_fma(p45.x, c - ec, -(p45.y * s));
-                    rv = div_fast(num, den) + C0;
-                }
-            } else {
-                // reduced precision: phase in fp64 (|M| ~ 1e4 rad, rvmodel:459), reduced to [-pi, pi]
-                // in fp64, then the same Newton rule (start E = M, stop |dE| <= tol, >= 1 step) in fp32
-                const double M = p01.x * (t - p01.y) + p23.x;
-                const float Mf = reduce_2pi_to_f32(M);
-                const float ecf = (float)ec, tolf = (float)a.tol;
-                float E = Mf, s, c, dE;
-                int steps = 0;
-                do {
-                    sincos_f32(E, s, c);
-                    const float f  = E - ecf * s - Mf;
-                    const float fp = 1.0f - ecf * c;
-                    const float En = E - div_f32(f, fp);
-                    dE = En - E;
-                    E = En;
-                    ++steps;
-                } while (fabsf(dE) > tolf && steps < a.itmax);
-                if (steps >= a.itmax) {
-                    atomicMin(&cx.jfail[pl * a.Np + ip], j);
-                    atomicOr(&cx.anyfail[pl], 1);
-                    atomicOr(cx.nfail, 1);
-                    rv = p45.x + C0;
-                } else {
-                    sincos_f32(E, s, c);
-                    const float den = __builtin_fmaf(-ecf, c, 1.0f);
-                    const float num = __builtin_fmaf((float)p45.x, c - ecf, -((float)p45.y * s));
-                    rv = (double)(div_f32(num, den) + (float)C0);
-                }
-            }
-            ksum += rv;                                                     // rvmodel:383
-        }
-        rvm += ksum;                                                        // rvmodel:199
-    }
-
-    if (a.has_drift) {                                                      // rvmodel:242-271
-        const double* d = cx.dr + pl * 6;
-        const double tt = (t - d[4]) * (1.0 / 365.25);
-        const double t2 = tt * tt;
-        rvm += d[0] * tt + d[1] * t2 + d[2] * (t2 * tt) + d[3] * (t2 * t2);
-    }
-    for (int k = 0; k < a.nlin; ++k)                                        // rvmodel:210-212
-        rvm += cx.lin[pl * a.nlin + k] * a.linpar[(size_t)k * a.Ne + j];
-
-    const double res = y - rvm;                                             // rvmodel:215
-    if constexpr (PREC == RVLL_PREC_FP32) {
-        const float rf = (float)res, vf = (float)var;
-        return (double)(0.5f * __logf(vf) + div_f32(rf * rf, 2.0f * vf));
-    } else {
-        return 0.5 * log_pos(var) + div_fast(res * res, 2 * var);           // rvmodel:80
-    }
-}
-
-#ifndef RVLL_DECODE_INLINE
-#define RVLL_DECODE_INLINE __forceinline__
-#endif
-// LDS views of one workgroup's tile (carve()).
-struct TileLds {
-    double *theta_s, *pp, *ins, *dr, *lin, *acc, *lay, *contrib;
-    int *nfail, *ticket, *pflags, *anyfail, *jfail;
-};
-__device__ __forceinline__ TileLds tile_views(const LoglikeArgs& a, double* smem)
-{
-    const Carve cv = carve(a.PB, a.D, a.Np, a.Ni, a.nlin, a.CH);
-    TileLds L;
-    L.theta_s = smem + cv.theta;  L.pp = smem + cv.pp;    L.ins = smem + cv.ins;  L.dr = smem + cv.dr;
-    L.lin = smem + cv.lin;        L.acc = smem + cv.acc;  L.lay = smem + cv.lay;  L.contrib = smem + cv.contrib;
-    int* ints = reinterpret_cast<int*>(smem + cv.ints);
-    L.nfail = ints;  L.ticket = ints + 1;  L.pflags = ints + 2;  L.anyfail = L.pflags + a.PB;  L.jfail = L.anyfail + a.PB;
-    return L;
-}
-
-// 1. stage the tile's theta rows (one contiguous, coalesced span) + the layout structs + init.  Fused form: the rows
-//    are unit-cube coordinates and go through the prior transform on the way in (light kinds element by element,
-//    then the iterative kinds compacted so that consecutive lanes all run a solve); theta is written back.
-template <bool FUSED, int NT>
-__device__ __forceinline__ void tile_stage(const LoglikeArgs& __restrict__ a, const TileLds& L, long long p0, int npts,
-                                           unsigned long long* stamp = nullptr)
-{
-    const int tid = threadIdx.x;
-    if (FUSED) {
-        const double* src = a.cube + p0 * a.D;
-        double* dst = a.theta_out + p0 * a.D;
-        for (int i = tid; i < npts * a.D; i += NT) {
-            const int pl = i / a.D, d = i - pl * a.D;
-            if (prior_is_heavy(a.priors[d].kind)) continue;
-            const double v = prior_light(a.priors, a.D, src + pl * a.D, d);
-            L.theta_s[i] = v;
-            dst[i] = v;
-        }
-        for (int i = tid; i < npts * a.n_heavy; i += NT) {
-            const int pl = i / a.n_heavy;
-            const int d = a.heavy_dims[i - pl * a.n_heavy];
-            const double v = prior_heavy(a.priors[d], src[pl * a.D + d]);
-            L.theta_s[pl * a.D + d] = v;
-            dst[pl * a.D + d] = v;
-        }
-    } else {
-        const double* src = a.theta + p0 * a.D;
-        for (int i = tid; i < npts * a.D; i += NT) L.theta_s[i] = src[i];
-        if (stamp && tid == 0) {                    // diagnostic builds: theta has landed in this wave
-            __builtin_amdgcn_s_waitcnt(0);
-            *stamp = __builtin_amdgcn_s_memrealtime();
-        }
-    }
-    // the layout structs (planets, instruments, linear-term slots: one device blob) ride along, so that the decode
-    // step reads LDS only — as dependent global loads they were most of a workgroup's prologue
-    for (int i = tid; i < layout_doubles(a.Np, a.Ni, a.nlin); i += NT) L.lay[i] = a.layblob[i];
-    for (int i = tid; i < npts; i += NT) { L.acc[i] = 0.; L.pflags[i] = 0; L.anyfail[i] = 0; }
-    for (int i = tid; i < npts * a.Np; i += NT) L.jfail[i] = 0x7fffffff;
-    if (tid == 0) { L.nfail[0] = 0; L.ticket[0] = 0; }
-}
-
-// 2. decode per-point scalars once (rvmodel:412-456, :181-192, :242-260): one lane per (point, planet) from the
-//    front of the workgroup, one lane per point for the instrument / drift / linear terms from its back, so the two
-//    kinds of work sit in different waves whenever the tile leaves room
-template <int NT>
-__device__ RVLL_DECODE_INLINE void tile_decode(const LoglikeArgs& __restrict__ a, const TileLds& L, int npts)
-{
-    const int tid = threadIdx.x;
-    const rvll_planet* lp = reinterpret_cast<const rvll_planet*>(L.lay);
-    const rvll_inst*   li = reinterpret_cast<const rvll_inst*>(L.lay + a.Np * kPlanetDoubles);
-    const rvll_slot*   ll = reinterpret_cast<const rvll_slot*>(L.lay + a.Np * kPlanetDoubles + a.Ni * kInstDoubles);
-    for (int wk = tid; wk < npts * a.Np; wk += NT) {
-        const int pl = wk / a.Np;
-        const int k  = wk - pl * a.Np;
-        const double* th = L.theta_s + pl * a.D;
-        const rvll_planet& d = lp[k];
-        const double kraw = slot_lds(&d.k, th);
-        const double praw = slot_lds(&d.p, th);
-        const double K = d.k_kind == RVLL_K_LOGK1 ? exp(kraw) : kraw;
-        const double Pd = d.p_kind == RVLL_P_LOGPERIOD ? exp(praw) : praw;
-        const double e1 = slot_lds(&d.e1, th);
-        const double e2 = slot_lds(&d.e2, th);
-        double ecc, omega;
-        if (d.ecc_kind == RVLL_ECC_SECOS_SESIN) {
-            ecc = e1 * e1 + e2 * e2;
-            omega = atan2(e2, e1);
-            if (ecc > 1) atomicOr(&L.pflags[pl], RVLL_FLAG_INVALID_ORBIT);
-        } else if (d.ecc_kind == RVLL_ECC_ECOS_ESIN) {
-            ecc = sqrt(e1 * e1 + e2 * e2);
-            omega = atan2(e2, e1);
-            if (ecc > 1) atomicOr(&L.pflags[pl], RVLL_FLAG_INVALID_ORBIT);
-        } else {
-            ecc = e1;
-            omega = e2;
-        }
-        const double anom = slot_lds(&d.anom, th);
-        const double ma0 = d.anom_kind == RVLL_ANOM_ML0 ? anom - omega : anom;
-        const double ec = ecc > 0.99 ? 0.99 : ecc;                  // trueanomaly.c:11-12
-        double so, co;
-        sincos_f64(omega, so, co);
-        const double q = sqrt((1. - ec) * (1. + ec));
-        double* P = L.pp + (pl * a.Np + k) * kPlanetFields;
-        P[0] = kTwoPi / Pd;
-        P[1] = slot_lds(&d.epoch, th);
-        P[2] = ma0;
-        P[3] = ec;
-        P[4] = K * co;
-        P[5] = K * q * so;
-        P[6] = K * (ecc * co);
-        P[7] = 0.;
-    }
-    for (int pl = NT - 1 - tid; pl < npts; pl += NT) {
-        const double* th = L.theta_s + pl * a.D;
-        for (int i = 0; i < a.Ni; ++i) {
-            L.ins[(pl * a.Ni + i) * 2] = slot_lds(&li[i].offset, th);
-            double j2 = 0.;
-            if (a.has_jitter) { const double jit = slot_lds(&li[i].jitter, th); j2 = jit * jit; }
-            L.ins[(pl * a.Ni + i) * 2 + 1] = j2;
-        }
-        if (a.has_drift) {
-            const rvll_slot* ld = ll + a.nlin;                  // drift[0..3], tref
-            double* d = L.dr + pl * 6;
-            d[0] = slot_lds(&ld[0], th);
-            d[1] = slot_lds(&ld[1], th);
-            d[2] = slot_lds(&ld[2], th);
-            d[3] = slot_lds(&ld[3], th);
-            d[4] = a.tref_from_data ? a.t[0] : slot_lds(&ld[4], th);
-            d[5] = 0.;
-        }
-        for (int k2 = 0; k2 < a.nlin; ++k2) L.lin[pl * a.nlin + k2] = slot_lds(&ll[k2], th);
-    }
-}
-
-// Per-point partial sums of the contributions [lo[k], hi[k]) of up to four points held in contrib[.. - base], each
-// in the fixed order every kernel form uses (lane-strided, then the shuffle tree), so the bits do not depend on the
-// launch geometry.  Four points go through the tree together: one point's six dependent cross-lane steps are
-// ~150 cycles of latency each and nothing else is runnable in a reduction phase.  Unused entries: lo == hi.
-__device__ __forceinline__ void point_partials4(const double* contrib, int base, const int (&lo)[4], const int (&hi)[4],
-                                                int lane, double (&v)[4])
-{
-    // lane-strided sums, four strides of every point in flight per pass.  Out-of-range slots add +0.0, which
-    // changes no partial sum (they start at +0.0 and can never become -0.0).
-    int nmax = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { v[k] = 0.; nmax = max(nmax, hi[k] - lo[k]); }
-    for (int t = lane; t < nmax; t += 4 * kWave) {
-        double x[4][4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int i = lo[k] + t + u * kWave;
-                x[k][u] = i < hi[k] ? contrib[i - base] : 0.;
-            }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = (((v[k] + x[k][0]) + x[k][1]) + x[k][2]) + x[k][3];
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = wave_sum_lane0(v[k]);
-}
-
-// 4. one log-L per live point
-__device__ __forceinline__ void tile_write_point(const LoglikeArgs& __restrict__ a, const TileLds& L, long long p0, int pl)
-{
-    int f = L.pflags[pl];
-    if (L.anyfail[pl]) f |= RVLL_FLAG_NONCONVERGED;
-    const bool invalid = (f & RVLL_FLAG_INVALID_ORBIT) != 0 && a.Np > 0;
-    a.logL[p0 + pl] = invalid ? -1e30 : a.cte - L.acc[pl];                 // rvmodel:203, :78-80
-    if (a.flags) a.flags[p0 + pl] = f;
-}
-
-// One tile of live points [p0, p0 + npts) by one workgroup of NT threads: stage, decode, items, reduce, write.
-// Shared by the batch kernels (tile = blockIdx), the walk and the scalar-call server (one point per request).
-//   NT = 256, DYN = false  the tile form: four such workgroups per CU, items dealt statically, LDS windows of a.CH
-//                          contributions (<= kTileWindow);
-//   NT = 1024, DYN = true  the CU-wide form: one workgroup fills the CU (16 waves = the same 4 per SIMD), ALL the
-//                          tile's items sit in LDS at once (a.CH >= a.PB * a.Ne, host-checked) and the waves draw
-//                          64-item rounds from an LDS ticket counter, so every wave stays busy until the tile's
-//                          items are gone.  Why: four independent 256-thread workgroups on a CU do not finish
-//                          together — VALU issue is arbitrated by age, the oldest runs fastest — so a launch ended
-//                          with 3, 2, then 1 workgroup per CU for a third of its duration at well under the 4-wave
-//                          issue rate (profiles/r02_wg_trace_cfg3.txt; two launches in flight, which backfill the
-//                          freed slots, ran 20 % faster per launch).
-// Every point's contributions are summed in the same order in both forms — slices at point-local multiples of
-// kTileWindow, each lane-strided then through the shuffle tree — so results are bit-identical across forms, tile
-// sizes and shard sizes.
-// TRACE: diagnostic build (launch_loglike_trace) — a few s_memrealtime stamps per workgroup go to a.trace, a
-// buffer nothing else reads; no stamp executes in the product kernels.
-template <int PREC, bool FUSED, bool TRACE = false, int NT = kThreads, bool DYN = false>
-__device__ __forceinline__ __attribute__((flatten)) void loglike_tile(const LoglikeArgs& __restrict__ a, double* __restrict__ smem, long long p0, int npts)
-{
-    unsigned long long* tr = nullptr;
-    if constexpr (TRACE) {
-        tr = a.trace + (size_t)blockIdx.x * kTraceWords;
-        if (threadIdx.x == 0) {
-            tr[0] = __builtin_amdgcn_s_memrealtime();
-            // s_getreg_b32 simm16 = (size-1) << 11 | offset << 6 | id; HW_REG_HW_ID = 4, HW_REG_XCC_ID = 20
-            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
-            const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
-            tr[7] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
-        }
-    }
-    const TileLds L = tile_views(a, smem);
-    const int tid  = threadIdx.x;
-    const int lane = tid & (kWave - 1);
-    const int wave = tid >> 6;
-    constexpr int NW = NT / kWave;
-
-    // The prologue is a short serial section (a few lanes, long dependent chains).  A young workgroup's waves get
-    // only the issue slots older ones leave (arbitration is by priority, then age), which stretched it 2.5x next
-    // to three workgroups in their item loops: run it at raised priority, the item loop at the default.
-    if constexpr (!DYN) __builtin_amdgcn_s_setprio(3);
-    tile_stage<FUSED, NT>(a, L, p0, npts, TRACE && DYN ? tr + 1 : nullptr);
-    __syncthreads();
-    if constexpr (TRACE && DYN) { if (tid == 0) tr[2] = __builtin_amdgcn_s_memrealtime(); }
-    tile_decode<NT>(a, L, npts);
-    __syncthreads();
-    if constexpr (!DYN) __builtin_amdgcn_s_setprio(0);
-    if constexpr (TRACE) { if (tid == 0) tr[DYN ? 3 : 1] = __builtin_amdgcn_s_memrealtime(); }
-
-    // 3. items: flattened (point, epoch) pairs of this block, CH at a time
-    const ItemCtx cx{L.pp, L.ins, L.dr, L.lin, L.nfail, L.anyfail, L.jfail};
-    double* contrib = L.contrib;
-    const int nitems = npts * a.Ne;
-    // LDS windows are cut at point-local positions — whole points while a point fits the window, otherwise
-    // every point by itself at multiples of CH — so each point's sum has one order whatever the tiling
-    const int wpts = a.Ne <= a.CH ? a.CH / a.Ne : 0;
-    for (int base = 0, cend; base < nitems; base = cend) {
-        cend = wpts ? min(base + wpts * a.Ne, nitems) : min(base + a.CH, (base / a.Ne + 1) * a.Ne);
-        if constexpr (DYN) {
-            // one window (host-checked): wave rounds of 64 consecutive items, drawn from the ticket counter
-            for (;;) {
-                int r = 0;
-                if (lane == 0) r = atomicAdd(L.ticket, 1);
-                r = __builtin_amdgcn_readfirstlane(r);
-                if (r * kWave >= cend) break;
-                const int i = r * kWave + lane;
-                if (i < cend) {
-                    const int pl = i / a.Ne;
-                    contrib[i] = eval_item<PREC>(a, cx, pl, i - pl * a.Ne);
-                }
-            }
-            if constexpr (TRACE) { if (tid == 0) tr[4] = __builtin_amdgcn_s_memrealtime(); }
-        } else {
-            for (int i = base + tid; i < cend; i += NT) {
-                const int pl = i / a.Ne;
-                const int j  = i - pl * a.Ne;
-                contrib[i - base] = eval_item<PREC>(a, cx, pl, j);
-            }
-            if constexpr (TRACE) { if (lane == 0) tr[2 + wave] = __builtin_amdgcn_s_memrealtime(); }
-        }
-        __syncthreads();
-        if constexpr (TRACE && DYN) { if (tid == 0) tr[5] = __builtin_amdgcn_s_memrealtime(); }
-        // 3b. rare: a solve hit itmax.  The reference aborts that planet's array there
-        // and leaves nu = 0 from that epoch on; redo the affected points' items now that
-        // the first failing epoch per (point, planet) is known.
-        if (L.nfail[0] != 0) {
-            for (int i = base + tid; i < cend; i += NT) {
-                const int pl = i / a.Ne;
-                if (L.anyfail[pl]) contrib[i - base] = eval_item<PREC>(a, cx, pl, i - pl * a.Ne);
-            }
-            __syncthreads();
-        }
-        // 3c. per-point partial sums of this window, fixed order (deterministic): the part of each point that
-        // lies in the window, slice by slice
-        const int pl_lo = base / a.Ne;
-        const int pl_hi = (cend - 1) / a.Ne;
-        const int nslices = (a.Ne + kTileWindow - 1) / kTileWindow;
-        for (int pl0 = pl_lo + wave; pl0 <= pl_hi; pl0 += 4 * NW) {
-            for (int sl = 0; sl < nslices; ++sl) {
-                int lo[4], hi[4];
-                double v[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int pl = pl0 + k * NW;
-                    const int first = pl * a.Ne + sl * kTileWindow;                  // this slice of this point
-                    const int l = max(base, first), h = min(min(cend, (pl + 1) * a.Ne), first + kTileWindow);
-                    const bool any = pl <= pl_hi && l < h;
-                    lo[k] = any ? l : 0;
-                    hi[k] = any ? h : 0;
-                }
-                point_partials4(contrib, base, lo, hi, lane, v);
-                if (lane == 0) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) if (lo[k] < hi[k]) L.acc[pl0 + k * NW] += v[k];
-                }
-            }
-        }
-        __syncthreads();
-    }
-
-    for (int pl = tid; pl < npts; pl += NT) tile_write_point(a, L, p0, pl);
-    if constexpr (TRACE) {
-        __syncthreads();
-        if (threadIdx.x == 0) tr[6] = __builtin_amdgcn_s_memrealtime();
-    }
-}
 
 // The CU-wide form: one 1024-thread workgroup per tile of a.PB points (loglike_tile, NT = 1024, DYN)
 template <int PREC, bool TRACE>
@@ -651,11 +32,12 @@ void loglike_cu_kernel(const LoglikeArgs a)
     const long long p0 = (long long)blockIdx.x * a.PB;
     const int npts = (int)min((long long)a.PB, a.B - p0);
     if (npts <= 0) return;
-    loglike_tile<PREC, false, TRACE, kCuThreads, true>(a, smem, p0, npts);
+    loglike_tile<PREC, kFusedNone, TRACE, kCuThreads, true>(a, smem, p0, npts);
 }
 
 // 4 workgroups of 256 per CU (4 waves/SIMD): caps the kernel at 128 VGPRs
-template <int PREC, bool FUSED>
+// FUSED: kFusedNone (theta rows in) or kFusedSlim (unit-cube rows in, verified-table quantiles; rvll_tile.h)
+template <int PREC, int FUSED>
 __global__ __launch_bounds__(kThreads, 4) __attribute__((flatten))      // flatten: the prior routines of the fused
 void loglike_kernel(const LoglikeArgs a)                                // form must live under the same VGPR cap
 {
@@ -666,7 +48,7 @@ void loglike_kernel(const LoglikeArgs a)                                // form 
     loglike_tile<PREC, FUSED>(a, smem, p0, npts);
 }
 
-// Diagnostic twin of loglike_kernel<RVLL_PREC_FP64, false>: same tile, same launch bounds, plus the stamps.
+// Diagnostic twin of loglike_kernel<RVLL_PREC_FP64, kFusedNone>: same tile, same launch bounds, plus the stamps.
 __global__ __launch_bounds__(kThreads, 4) __attribute__((flatten))
 void loglike_trace_kernel(const LoglikeArgs a)
 {
@@ -674,151 +56,7 @@ void loglike_trace_kernel(const LoglikeArgs a)
     const long long p0 = (long long)blockIdx.x * a.PB;
     const int npts = (int)min((long long)a.PB, a.B - p0);
     if (npts <= 0) return;
-    loglike_tile<RVLL_PREC_FP64, false, true>(a, smem, p0, npts);
-}
-
-// Device-resident slice-sampling walk (rvll_kernels.h, WalkArgs; the scheme of evidence_amd/nested.py
-// run_nested_slice, which follows the reference's UltraNest wrapper: region slice sampling, nsteps moves per new
-// point, circular omega / ml0 — evidence/ultranest/__init__.py:159-175).  Everything a move needs stays on the
-// chip: counter-based random numbers, directions, chords, candidates (written to the workgroup's scratch rows),
-// prior transform + log-L of the candidates through the same loglike_tile as every other path, accept / shrink.
-// The walkers of a workgroup are NOT in lock step: every iteration evaluates one candidate for every walker that
-// still has moves left, and a walker whose candidate was accepted draws its next direction in the following
-// iteration — so the tile stays full until the walkers run out of moves (their totals over nsteps moves are
-// close), instead of idling behind the slowest walker of every move.  Trip counts are bounded by
-// nsteps * max_rounds and shared through LDS, so all waves loop alike.
-template <int PREC>
-__global__ __launch_bounds__(kThreads, 2) __attribute__((flatten))      // 256 VGPRs: prior routines + tile in one loop nest
-void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
-{
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const Carve cv = carve(a.PB, a.D, a.Np, a.Ni, a.nlin, a.CH);
-    const int D = a.D, PB = a.PB, tid = threadIdx.x;
-    const long long w0 = (long long)blockIdx.x * PB;
-    const int nw = (int)min((long long)PB, w.K - w0);
-    if (nw <= 0) return;
-    double* wu   = smem + ((cv.total_doubles + 1) & ~1);   // [PB][D] current positions
-    double* dir  = wu + PB * D;                            // [PB][D] normals, then unit directions
-    double* tmin = dir + PB * D;                           // [PB]
-    double* tmax = tmin + PB;
-    double* tcur = tmax + PB;
-    double* wl   = tcur + PB;
-    int* act     = reinterpret_cast<int*>(wl + PB);         // [PB] walkers with moves left (local index), compacted
-    int* state   = act + PB;                                // [PB] 0: needs a new direction, 1: in a move, 2: accepted just now
-    int* step_of = state + PB;                              // [PB] moves completed
-    int* round_of = step_of + PB;                           // [PB] candidates tried in the current move
-    int* nact_s  = round_of + PB;                           // [1]
-    const double one_below = 0.99999999999999988898;        // nextafter(1, 0)
-
-    for (int i = tid; i < nw * D; i += kThreads) wu[i] = w.u[w0 * D + i];
-    for (int i = tid; i < nw; i += kThreads) { wl[i] = w.logl[w0 + i]; state[i] = 0; step_of[i] = 0; round_of[i] = 0; act[i] = i; }
-    if (tid == 0) nact_s[0] = nw;
-    unsigned long long calls = 0;                           // thread 0 only
-    __syncthreads();
-
-    const long long max_iters = (long long)w.nsteps * w.max_rounds;
-    for (long long iter = 0; iter < max_iters; ++iter) {
-        const int nact = nact_s[0];
-        if (nact == 0) break;
-        // walkers starting a move: standard normals (Box-Muller on two counter-based uniforms) ...
-        for (int i = tid; i < nact * D; i += kThreads) {
-            const int pl = act[i / D], k = i % D;
-            if (state[pl] != 0) continue;
-            const unsigned long long ctr = ((unsigned long long)(w0 + pl) << 32) | ((unsigned long long)step_of[pl] << 14) | (unsigned)(2 * k);
-            const double u1 = uniform01(w.seed, ctr), u2 = uniform01(w.seed, ctr + 1);
-            double sn, cs;
-            sincos_f64(kTwoPi * u2, sn, cs);
-            dir[pl * D + k] = sqrt(-2. * log(1. - u1)) * cs;
-        }
-        __syncthreads();
-        // ... direction = chol * z (lower triangular; held in registers until every z has been read) ...
-        double mine[4];                                     // PB * D <= 4 * kThreads
-        int cnt = 0;
-        for (int i = tid; i < nact * D; i += kThreads, ++cnt) {
-            const int pl = act[i / D], k = i % D;
-            if (state[pl] != 0) continue;
-            double acc = 0.;
-            for (int j = 0; j <= k; ++j) acc += w.chol[k * D + j] * dir[pl * D + j];
-            mine[cnt & 3] = acc;
-        }
-        __syncthreads();
-        cnt = 0;
-        for (int i = tid; i < nact * D; i += kThreads, ++cnt) {
-            const int pl = act[i / D], k = i % D;
-            if (state[pl] == 0) dir[pl * D + k] = mine[cnt & 3];
-        }
-        __syncthreads();
-        // ... normalise, chord (one thread per walker); then the candidate position along the chord
-        for (int ai = tid; ai < nact; ai += kThreads) {
-            const int pl = act[ai];
-            if (state[pl] == 0) {
-                double n2 = 0.;
-                for (int k = 0; k < D; ++k) n2 += dir[pl * D + k] * dir[pl * D + k];
-                const double inv = 1. / sqrt(n2);
-                double lo = -INFINITY, hi = INFINITY;
-                for (int k = 0; k < D; ++k) {
-                    const double d = dir[pl * D + k] * inv, u = wu[pl * D + k];
-                    dir[pl * D + k] = d;
-                    if (d == 0.) continue;
-                    if (w.wrapped[k]) {
-                        const double half = 0.5 / fabs(d);
-                        lo = fmax(lo, -half); hi = fmin(hi, half);
-                    } else {
-                        const double t0 = (0. - u) / d, t1 = (1. - u) / d;
-                        lo = fmax(lo, fmin(t0, t1)); hi = fmin(hi, fmax(t0, t1));
-                    }
-                }
-                tmin[pl] = lo; tmax[pl] = hi;
-                round_of[pl] = 0;
-                state[pl] = 1;
-            }
-            const unsigned long long ctr = ((unsigned long long)(w0 + pl) << 32) | ((unsigned long long)step_of[pl] << 14) |
-                                           (unsigned)(8192 + round_of[pl]);
-            tcur[pl] = tmin[pl] + (tmax[pl] - tmin[pl]) * uniform01(w.seed, ctr);
-        }
-        __syncthreads();
-        double* crow = const_cast<double*>(a.cube) + w0 * D;           // this workgroup's scratch rows
-        for (int i = tid; i < nact * D; i += kThreads) {
-            const int ai = i / D, k = i - ai * D, pl = act[ai];
-            double c = wu[pl * D + k] + tcur[pl] * dir[pl * D + k];
-            if (w.wrapped[k]) c -= floor(c);
-            crow[ai * D + k] = fmin(fmax(c, 0.), one_below);
-        }
-        __syncthreads();
-        loglike_tile<PREC, true>(a, smem, w0, nact);                   // prior transform + log-L of the candidates
-        __syncthreads();
-        for (int ai = tid; ai < nact; ai += kThreads) {
-            const int pl = act[ai];
-            const double cl = a.logL[w0 + ai];
-            if (cl > w.lstar) { state[pl] = 2; wl[pl] = cl; }
-            else {
-                if (tcur[pl] < 0.) tmin[pl] = tcur[pl]; else tmax[pl] = tcur[pl];
-                if (++round_of[pl] >= w.max_rounds) { state[pl] = 0; step_of[pl] += 1; }   // give the move up, stay put
-            }
-        }
-        __syncthreads();
-        for (int i = tid; i < nact * D; i += kThreads) {
-            const int ai = i / D, k = i - ai * D, pl = act[ai];
-            if (state[pl] != 2) continue;
-            wu[pl * D + k] = crow[ai * D + k];
-            w.theta[(w0 + pl) * D + k] = a.theta_out[(w0 + ai) * D + k];
-        }
-        __syncthreads();
-        if (tid == 0) {
-            calls += (unsigned long long)nact;
-            int n = 0;
-            for (int ai = 0; ai < nact; ++ai) {
-                const int pl = act[ai];
-                if (state[pl] == 2) { state[pl] = 0; step_of[pl] += 1; }
-                if (step_of[pl] < w.nsteps) act[n++] = pl;
-            }
-            nact_s[0] = n;
-        }
-        __syncthreads();
-    }
-    for (int i = tid; i < nw * D; i += kThreads) w.u[w0 * D + i] = wu[i];
-    for (int i = tid; i < nw; i += kThreads) w.logl[w0 + i] = wl[i];
-    if (tid == 0 && calls) atomicAdd(w.ncalls, calls);
+    loglike_tile<RVLL_PREC_FP64, kFusedNone, true>(a, smem, p0, npts);
 }
 
 // Scalar-call server (rvll_kernels.h, ServerCtl).  Thread 0 polls the request word in host memory (system-scope
@@ -864,7 +102,7 @@ void scalar_server_kernel(const LoglikeArgs a, ServerCtl* ctl, unsigned long lon
             __threadfence_system();                   // every thread's theta stores are out before the answer
             __syncthreads();
         } else if (op == kServerLogLike) {
-            loglike_tile<PREC, false>(a, smem, 0, 1);
+            loglike_tile<PREC, kFusedNone>(a, smem, 0, 1);
             if (threadIdx.x == 0) {                   // thread 0 wrote a.logL[0] / a.flags[0] itself
                 ans.logL = __hip_atomic_load(a.logL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ans.flags = __hip_atomic_load(a.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1071,7 +309,7 @@ size_t loglike_lds_bytes(const LoglikeArgs& a)
 int loglike_blocks_per_cu(size_t lds_bytes)
 {
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, loglike_kernel<RVLL_PREC_FP64, false>, kThreads, lds_bytes) != hipSuccess || n < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, loglike_kernel<RVLL_PREC_FP64, kFusedNone>, kThreads, lds_bytes) != hipSuccess || n < 1)
         n = 1;
     return n > 8 ? 8 : n;
 }
@@ -1083,9 +321,9 @@ hipError_t launch_loglike(const LoglikeArgs& a, hipStream_t stream)
     const size_t lds = loglike_lds_bytes(a);
     const dim3 grid((unsigned)blocks), block(kThreads);
     switch (a.precision) {
-    case RVLL_PREC_MIXED: hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_MIXED, false>), grid, block, lds, stream, a); break;
-    case RVLL_PREC_FP32:  hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP32, false>), grid, block, lds, stream, a); break;
-    default:              hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP64, false>), grid, block, lds, stream, a); break;
+    case RVLL_PREC_MIXED: hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_MIXED, kFusedNone>), grid, block, lds, stream, a); break;
+    case RVLL_PREC_FP32:  hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP32, kFusedNone>), grid, block, lds, stream, a); break;
+    default:              hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP64, kFusedNone>), grid, block, lds, stream, a); break;
     }
     return hipGetLastError();
 }
@@ -1129,29 +367,6 @@ hipError_t launch_loglike_trace(const LoglikeArgs& a, hipStream_t stream)
     return hipGetLastError();
 }
 
-size_t walk_lds_bytes(const LoglikeArgs& a)
-{
-    const size_t base = (loglike_lds_bytes(a) + 15) & ~(size_t)15;
-    return base + sizeof(double) * ((size_t)2 * a.PB * a.D + 4 * a.PB) + sizeof(int) * (4 * a.PB + 2) + 16;
-}
-
-hipError_t launch_slice_walk(const LoglikeArgs& a, const WalkArgs& w, hipStream_t stream)
-{
-    if (w.K <= 0 || w.nsteps <= 0) return hipSuccess;
-    if (!a.cube || !a.theta_out || !a.priors || a.PB * a.D > 4 * kThreads || w.nsteps >= (1 << 18) ||
-        w.max_rounds < 1 || w.max_rounds > 4096 || a.D > 4096)
-        return hipErrorInvalidValue;
-    const size_t lds = walk_lds_bytes(a);
-    if (lds > 64 * 1024) return hipErrorInvalidValue;
-    const dim3 grid((unsigned)((w.K + a.PB - 1) / a.PB)), block(kThreads);
-    switch (a.precision) {
-    case RVLL_PREC_MIXED: hipLaunchKernelGGL((slice_walk_kernel<RVLL_PREC_MIXED>), grid, block, lds, stream, a, w); break;
-    case RVLL_PREC_FP32:  hipLaunchKernelGGL((slice_walk_kernel<RVLL_PREC_FP32>), grid, block, lds, stream, a, w); break;
-    default:              hipLaunchKernelGGL((slice_walk_kernel<RVLL_PREC_FP64>), grid, block, lds, stream, a, w); break;
-    }
-    return hipGetLastError();
-}
-
 hipError_t launch_scalar_server(const LoglikeArgs& a, ServerCtl* ctl, unsigned long long last,
                                 unsigned long long idle_ticks, hipStream_t stream)
 {
@@ -1174,9 +389,9 @@ hipError_t launch_prior_loglike(const LoglikeArgs& a, hipStream_t stream)
     const size_t lds = loglike_lds_bytes(a);
     const dim3 grid((unsigned)blocks), block(kThreads);
     switch (a.precision) {
-    case RVLL_PREC_MIXED: hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_MIXED, true>), grid, block, lds, stream, a); break;
-    case RVLL_PREC_FP32:  hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP32, true>), grid, block, lds, stream, a); break;
-    default:              hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP64, true>), grid, block, lds, stream, a); break;
+    case RVLL_PREC_MIXED: hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_MIXED, kFusedSlim>), grid, block, lds, stream, a); break;
+    case RVLL_PREC_FP32:  hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP32, kFusedSlim>), grid, block, lds, stream, a); break;
+    default:              hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP64, kFusedSlim>), grid, block, lds, stream, a); break;
     }
     return hipGetLastError();
 }
@@ -1197,6 +412,7 @@ hipError_t launch_prior(const PriorArgs& a, hipStream_t stream)
 }
 
 int prior_table_nodes() { return kTableN; }
+double prior_table_umax() { return kTableU; }
 
 hipError_t launch_prior_table(int kind, const double* args, double* z, double* dz, unsigned long long* max_err_bits,
                               hipStream_t stream)

@@ -311,6 +311,10 @@ class GpuRVModel:
         """Launch form of the log-L kernel: "auto" (by batch size), "tile" or "cu" (include/rvll.h); same bits."""
         _abi.check(self._lib.rvll_set_kernel_form(self._h, {"auto": 0, "tile": 1, "cu": 2}[form]))
 
+    def set_slim_table_range(self, umax):
+        """Test hook (include/rvll.h): |logit q| range the table-only prior stage takes before handing over."""
+        _abi.check(self._lib.rvll_set_slim_table_range(self._h, float(umax)))
+
     def debug_eval(self, op, x, y=None):
         """Evaluate one device math routine elementwise (include/rvll.h, diagnostics)."""
         x = np.ascontiguousarray(x, dtype=np.float64)

@@ -352,6 +352,12 @@ int rvll_debug_eval(rvll_handle* h, int32_t op, const double* x, const double* y
 int rvll_dev_trace_loglike(rvll_handle* h, int64_t B, int32_t warmup, uint64_t* out, int64_t out_words,
                            int32_t* blocks, int32_t* points_per_block);
 
+/* The kernels that carry a log-L tile next to the prior stage (one-launch cube -> log-L, the walk) evaluate Beta /
+ * Gamma quantiles by their verified tables over |logit q| <= umax (default: the whole table, 30) and hand every
+ * other element to the routines with the full solvers — same results either way.  Lowering umax (0: nothing is
+ * taken by the tables) exists so that tests can drive that hand-over; no reference counterpart.               */
+int rvll_set_slim_table_range(rvll_handle* h, double umax);
+
 /* ---- housekeeping ---------------------------------------------------------- */
 const char* rvll_last_error(void);
 int rvll_version(int32_t* major, int32_t* minor);

@@ -14,8 +14,8 @@ FLAGS = "-O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -fvisibili
 
 def main():
     rows = []
-    for src in ("rvll_kernels.hip", "rvll_fip.hip"):
-        cmd = f"/opt/rocm/bin/hipcc {FLAGS} -Rpass-analysis=kernel-resource-usage -c {src} -o /dev/null"
+    for src, extra in (("rvll_kernels.hip", ""), ("rvll_walk.hip", "-mllvm -disable-machine-licm"), ("rvll_fip.hip", "")):
+        cmd = f"/opt/rocm/bin/hipcc {FLAGS} {extra} -Rpass-analysis=kernel-resource-usage -c {src} -o /dev/null"
         err = subprocess.run(cmd, shell=True, cwd=CSRC, capture_output=True, text=True).stderr
         cur = None
         for line in err.splitlines():

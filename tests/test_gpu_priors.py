@@ -164,3 +164,43 @@ def test_sorted_loguniform_against_oracle(gpu_required):
         got = m.prior_transform_batch(cube)
     want = po.sorted_uniform(cube[:, idx], 1.5, 1000.0, log=True)
     assert pc.rel_err(got[:, idx], want).max() <= 1e-13
+
+
+@pytest.mark.parametrize("umax", [None, 3.0, 0.0])
+def test_slim_prior_stage_hands_over_what_its_tables_do_not_cover(gpu_required, umax):
+    """The one-launch cube -> log-L kernel evaluates Beta / Gamma quantiles by their verified tables only
+    (|logit q| <= 30) and leaves every other element — q = 0, q = 1, the far tails, anything when the range is
+    lowered — to the prior kernels with the full solvers: whatever the route, the result is what
+    prior_transform_batch + log_likelihood_batch return, bit for bit."""
+    from evidence_amd import priors as P
+    w = make_workload(3)
+    pri = w.priordict()
+    pri["hires_jitter"] = P.Gamma(2.0, 0.7)
+    rng = np.random.default_rng(5)
+    cube = rng.random((600, w.ndim))
+    ecc = [w.parnames.index(f"planet{k}_ecc") for k in (1, 2, 3)]
+    gam = w.parnames.index("hires_jitter")
+    cube[0, ecc[0]] = 0.0
+    cube[1, ecc[1]] = 1.0 - 2.0 ** -53
+    cube[2, ecc[2]] = 1e-15
+    cube[3, gam] = 1e-300
+    cube[4, gam] = 1.0 - 1e-15
+    cube[5, ecc[0]] = 1e-13
+    with GpuRVModel(w.fixedpardict, w.table, w.parnames, priordict=pri) as m:
+        if umax is not None:
+            m.set_slim_table_range(umax)
+        theta2 = m.prior_transform_batch(cube)
+        logl2 = m.log_likelihood_batch(theta2)
+        for n in (6, 40, 600):                                           # zero-copy small batch, pinned staging, plain
+            theta, logl = m.prior_loglike_batch(cube[:n])
+            assert np.array_equal(theta, theta2[:n], equal_nan=True) and np.array_equal(logl, logl2[:n], equal_nan=True), n
+            m.dev_upload_cube(cube[:n])
+            m.dev_prior_loglike(n)
+            th3, ll3, fl3 = m.dev_download(n, theta=True, flags=True)
+            assert np.array_equal(th3, theta2[:n], equal_nan=True) and np.array_equal(ll3, logl2[:n], equal_nan=True), n
+            assert not (fl3 & ~3).any()                                   # the internal deferral bit never leaves
+        # and a batch the tables cover entirely still takes the one launch and agrees
+        inner = rng.random((300, w.ndim))
+        t4, l4 = m.prior_loglike_batch(inner)
+        assert np.array_equal(l4, m.log_likelihood_batch(m.prior_transform_batch(inner)))
+    assert np.isfinite(theta2[6:]).all()

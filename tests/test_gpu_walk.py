@@ -146,3 +146,26 @@ def test_51peg_evidence_device_walk_agrees_with_host_walk(gpu_required):
         ip, ik = m.parnames.index("planet1_period"), m.parnames.index("planet1_k1")
         assert abs(np.sum(wgt * d.samples[:, ip]) - 4.2308) < 0.01
         assert abs(np.sum(wgt * d.samples[:, ik]) - 56.0) < 6.0
+
+
+def test_slim_walk_with_fat_finish_is_the_fat_walk(gpu_required, monkeypatch):
+    """The walk's fast instantiation evaluates Beta / Gamma quantiles by their verified tables only; a walker whose
+    candidate needs more stops at the start of that move and the instantiation with the full solvers finishes it,
+    retracing the interrupted move from the same counter-based random numbers.  Whatever share of the walkers takes
+    that route — none (default range), about half of the candidates (|logit q| <= 1), all of them (range 0) — the
+    end points are those of the full-solver walk alone."""
+    w = make_workload(3)
+    with GpuRVModel(w.fixedpardict, w.table, w.parnames, priordict=w.priordict()) as m:
+        cube, theta, logl, lstar, chol = _start(m, w, 1500, seed=21)
+        wr = wrapped_params(m.parnames)
+        monkeypatch.setenv("RVLL_WALK_FAT", "1")
+        ref = m.slice_walk(cube, theta, logl, lstar, chol, wr, nsteps=9, seed=4)
+        monkeypatch.delenv("RVLL_WALK_FAT")
+        got = {}
+        for umax in (30.0, 1.0, 0.0):
+            m.set_slim_table_range(umax)
+            got[umax] = m.slice_walk(cube, theta, logl, lstar, chol, wr, nsteps=9, seed=4)
+    for umax, g in got.items():
+        assert np.array_equal(g[0], ref[0]) and np.array_equal(g[1], ref[1]) and np.array_equal(g[2], ref[2]), umax
+    assert got[30.0][3] == ref[3]                 # nothing deferred: the same number of likelihood calls
+    assert got[0.0][3] >= ref[3]                  # everything deferred at its first candidate, then redone
