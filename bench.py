@@ -7,8 +7,11 @@
 
 A step = one pass of the hot path over one batch: the fused log-L kernel over B live points
 already resident in HBM (theta uploaded before the timed region), followed — for N > 1 — by
-the all-gather of the per-shard log-L to every rank, on a second HIP stream so that it overlaps
-the next step's kernel.  Weak scaling: B live points PER GPU, fixed as N grows.
+the RCCL all-gather of the per-shard log-L to every rank, in-stream behind the kernel; with
+pipeline lanes consecutive steps alternate streams / communicators so that the gather of one
+step overlaps the kernel of the next.  Weak scaling: B live points PER GPU, fixed as N grows.
+No torch anywhere: the ranks meet over evidence_amd/rendezvous.py (a process that imports torch
+first binds torch's bundled HIP runtime and RCCL instead of the ROCm ones librvll is built for).
 
 Workload: BASELINE.json configs[2] — 3-planet Keplerian, 200 epochs, 2 instruments with
 jitter + offset, 16384 live points (the configuration the >= 1e8 evals/s target is quoted on).
@@ -97,29 +100,45 @@ def cpu_model():
 
 def cpu_baseline(w, layout, theta, gpu_logl, seconds):
     """The oracle (C restatement of the reference path) on this node's host cores, OpenMP over live
-    points, on a bounded sample of the same workload.  Reported baseline, not the target."""
+    points, on a bounded sample of the same workload.  Reported baseline, not the target.
+
+    SURVEY §8(d) asks for all host cores, and the cgroup's cpu.max understates what a one-GPU job gets on the pool's
+    boxes (round 1: 16 by the quota, yet 128 threads ran 6x faster), so the thread count is SWEPT — 1, the cgroup
+    share, 64, 128, every logical CPU — for an equal slice of `seconds` each, and the best is the value reported;
+    the whole sweep is listed beside it."""
     from oracle import oracle as orc            # checker + CPU baseline only
     om = orc.OracleModel(layout, w.table)
-    threads = host_cpu_share()
     n = theta.shape[0]
-    ref = om.loglike(theta, nthreads=threads)   # warm + parity sample
+    logical = os.cpu_count() or 1
+    if os.environ.get("RVLL_CPU_THREADS"):
+        counts = [host_cpu_share()]
+    else:
+        counts = sorted({c for c in (1, host_cpu_share(), 64, 128, logical) if 1 <= c <= logical})
+    ref = om.loglike(theta, nthreads=counts[-1])   # warm + parity sample
     err = np.abs(gpu_logl - ref) / np.maximum(np.abs(ref), 1e-300)
-    done, t0 = 0, time.perf_counter()
-    while True:
-        om.loglike(theta, nthreads=threads)
-        done += n
-        el = time.perf_counter() - t0
-        if el >= seconds:
-            break
-    t1 = time.perf_counter()
-    om.loglike(theta[: max(1, n // 8)], nthreads=1)
-    one = (max(1, n // 8)) / (time.perf_counter() - t1)
+    slice_s = max(0.5, seconds / len(counts))
+    swept = {}
+    for c in counts:
+        sub = theta if c > 1 else theta[: max(1, n // 8)]      # one thread: a slice of the batch per pass
+        done, t0 = 0, time.perf_counter()
+        while True:
+            om.loglike(sub, nthreads=c)
+            done += sub.shape[0]
+            el = time.perf_counter() - t0
+            if el >= slice_s:
+                break
+        swept[c] = {"evals_per_s": done / el, "evaluations": done, "seconds": el}
+    best = max(swept, key=lambda c: swept[c]["evals_per_s"])
     iters = np.concatenate([om.iteration_counts(theta[i]).ravel() for i in range(0, n, max(1, n // 64))])
+    b = swept[best]
     return {
-        "value": done / el, "unit": "evals/s", "cores": threads, "kind": "port",
-        "sample": f"{done} evaluations ({done // n} passes over the same {n}-point batch, {el:.1f} s)",
-        "single_thread_evals_per_s": one,
-        "host_logical_cpus": os.cpu_count(), "cpu_model": cpu_model(),
+        "value": b["evals_per_s"], "unit": "evals/s", "cores": best, "kind": "port",
+        "sample": f"{b['evaluations']} evaluations (passes over the same {n}-point batch, {b['seconds']:.1f} s at {best} threads; "
+                  f"{len(counts)} thread counts tried for {slice_s:.1f} s each)",
+        "threads_swept": {str(c): round(v["evals_per_s"], 1) for c, v in swept.items()},
+        "single_thread_evals_per_s": swept[1]["evals_per_s"] if 1 in swept else None,
+        "cgroup_cpu_share": host_cpu_share(),
+        "host_logical_cpus": logical, "cpu_model": cpu_model(),
     }, float(err.max()), float(iters.mean())
 
 
@@ -139,24 +158,49 @@ class stdout_to_stderr:
         os.close(self._saved)
 
 
-def call_with_timeout(fn, seconds):
-    """Run fn() in a daemon thread (the ctypes calls release the GIL) and give up after `seconds`: a stuck RCCL
-    bootstrap must not hang the whole scaling run.  Returns (value, error)."""
-    import threading
-    box = {}
+class Watchdog:
+    """A hung collective must not hang the scaling run.  Phases of the N > 1 run report progress with kick(); if
+    nothing is reported for `limit` seconds the watchdog thread prints the best line this rank can still vouch for —
+    on rank 0 the single-lane measurement if one completed, else a line that says `rccl-hung` — and leaves through
+    os._exit: threads stuck inside RCCL cannot be joined, and a GPU process must never be re-exec'ed."""
 
-    def run():
-        try:
-            box["value"] = fn()
-        except Exception as exc:                      # noqa: BLE001 - handed back to the caller
-            box["error"] = exc
+    def __init__(self, rank, limit):
+        import threading
+        self.rank, self.limit = rank, limit
+        self.last, self.phase = time.monotonic(), "start"
+        self.fallback_line = None            # rank 0: JSON of a completed, verified measurement
+        self.hung_line = None                # rank 0: JSON skeleton for the nothing-completed case
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self._thread.start()
 
-    t = threading.Thread(target=run, daemon=True)
-    t.start()
-    t.join(seconds)
-    if t.is_alive():
-        return None, TimeoutError(f"no answer after {seconds:.0f} s")
-    return box.get("value"), box.get("error")
+    def kick(self, phase=None):
+        self.last = time.monotonic()
+        if phase:
+            self.phase = phase
+
+    def _run(self):
+        while not self._stop.wait(1.0):
+            if time.monotonic() - self.last <= self.limit:
+                continue
+            print(f"[rank {self.rank}] watchdog: no progress for {self.limit:.0f} s in phase '{self.phase}'",
+                  file=sys.stderr, flush=True)
+            code = 3
+            if self.rank == 0:
+                if self.fallback_line is not None:
+                    line = dict(self.fallback_line)
+                    line["config"] = dict(line["config"], note=f"multi-lane phase '{self.phase}' hung; single-lane measurement reported")
+                    print(json.dumps(line), flush=True)
+                    code = 0
+                elif self.hung_line is not None:
+                    line = dict(self.hung_line)
+                    line["config"] = dict(line["config"], allgather="rccl-hung", hung_phase=self.phase)
+                    print(json.dumps(line), flush=True)
+            sys.stdout.flush()
+            os._exit(code)
+
+    def stop(self):
+        self._stop.set()
 
 
 def device_count():
@@ -167,19 +211,32 @@ def device_count():
     return n.value
 
 
+def kernel_source_sha():
+    """sha256 over the kernel sources the committed PMC record was measured with (profiles/pmc_traffic.json)."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("rvll_tile.h", "rvll_kernels.hip", "rvll_math.h"):
+        h.update((REPO / "evidence_amd" / "csrc" / name).read_bytes())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(cfg, batch):
     """HBM bytes per launch of the log-L kernel from the committed rocprofv3 PMC passes
     (profiles/pmc_traffic.json, written by scripts/profile_gpu.sh + scripts/pmc_summary.py):
     FETCH_SIZE and WRITE_SIZE are in KiB; gfx950 reports half the bytes of a coalesced read stream, so
-    the read side is doubled (MI355X_MICROARCH.md, HBM section).  None when no matching profile exists."""
+    the read side is doubled (MI355X_MICROARCH.md, HBM section).  The record is stamped with a hash of the kernel
+    sources it was measured with: (None, reason) when it does not match the configuration or the sources."""
     path = REPO / "profiles" / "pmc_traffic.json"
     try:
         rec = json.loads(path.read_text())
     except (OSError, ValueError):
-        return None
+        return None, "no profiles/pmc_traffic.json"
     if rec.get("cfg") != cfg or rec.get("batch") != batch:
-        return None
-    return (2.0 * rec["fetch_kib"] + rec["write_kib"]) * 1024.0
+        return None, "profiles/pmc_traffic.json is for another configuration"
+    if rec.get("kernel_source_sha") != kernel_source_sha():
+        return None, "profiles/pmc_traffic.json was measured with other kernel sources (stale): traffic dropped"
+    return ((2.0 * rec["fetch_kib"] + rec["write_kib"]) * 1024.0,
+            f"profiles/pmc_traffic.json: {rec.get('source', '?')}")
 
 
 def fip_extra(with_cpu):
@@ -297,6 +354,211 @@ def run_extras(out, model, w, theta, B, with_cpu):
         guarded(name, fn)
 
 
+def build_line(args, w, model, B, world, elapsed, gather, lanes, timed_region_kernel_ms):
+    """The contract line (rank 0).  Returns (dict, gpu log-L of the resident batch, kernel seconds)."""
+    value = world * B * args.steps / elapsed
+    # dominant kernel, measured live with HIP events on the stream it is launched on
+    tm = model.dev_time_loglike(B, warmup=max(3, args.warmup // 4), iters=max(10, min(args.steps, 200)))
+    _, gpu_logl, _ = model.dev_download(B, flags=True)
+    # the roofline uses the launch duration over the TIMED REGION itself (HIP events around its K launches on
+    # their stream); the per-launch statistics of a separate event-per-launch run are reported beside it
+    kern_s = (timed_region_kernel_ms if timed_region_kernel_ms is not None else tm["kernel_ms_mean"]) * 1e-3
+    abytes = algorithmic_bytes_per_launch(w.ndim, w.table.n_epochs, B)
+    achieved = abytes / kern_s / 1e9
+    traffic, traffic_source = pmc_traffic(args.config, B)
+    form = "CU-wide (one 1024-thread workgroup per CU)" if tm["threads"] == 1024 else "256-thread tiles"
+    if world == 1:
+        structure = "one stream: launch k+1 starts when launch k has drained (value == B / kernel time)"
+    elif lanes > 1:
+        structure = (f"{lanes} pipeline lanes (stream + communicator + buffers each): kernel ; all-gather in-stream, "
+                     "consecutive steps alternate lanes, so two launches are in flight; the N=1 equivalent is "
+                     "two_lane_pipelined_evals_per_s of the N=1 line")
+    else:
+        structure = "one lane: kernel ; all-gather in one stream, the next kernel starts behind the gather"
+    out = {
+        "metric": "live_point_logL_evals_per_sec", "value": value, "unit": "evals/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": {"fp64": "f64", "mixed": "f32 Newton / f64 phase+chi2 (NOT a parity mode)",
+                                         "fp32": "f32 / f64 phase+sum (NOT a parity mode)"}[args.precision],
+        "data": "synthetic",
+        "config": {"workload": WORKLOAD_TEXT[args.config].format(b=B), "cfg": args.config,
+                   "live_points_per_gpu": B, "epochs": w.table.n_epochs, "planets": len(model.layout.planets),
+                   "instruments": len(w.table.insts), "free_parameters": w.ndim,
+                   "parallelism": f"live-point shards x{world}", "allgather": gather, "lanes": lanes,
+                   "kernel_form": form, "step_structure": structure, "runtime": GpuRVModel.runtime_info()},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                     "kernel": "loglike_cu_kernel" if tm["threads"] == 1024 else "loglike_kernel",
+                     "kernel_ms_timed_region": kern_s * 1e3,     # what `achieved` is computed from
+                     "kernel_ms_mean": tm["kernel_ms_mean"],      # event-per-launch statistics (separate run)
+                     "kernel_ms_min": tm["kernel_ms_min"], "kernel_ms_median": tm["kernel_ms_median"],
+                     "algorithmic_bytes_per_launch": abytes,
+                     "points_per_block": tm["points_per_block"], "blocks": tm["blocks"], "threads_per_block": tm["threads"],
+                     "kernel_evals_per_s": B / kern_s,
+                     "note": "fused kernel is fp64-VALU bound, not HBM bound (DESIGN.md); see valu_fp64"},
+    }
+    return out, gpu_logl, kern_s
+
+
+def run_single(args, w, model, theta, B):
+    # untimed pre-warm so that a short --warmup still starts from ramped clocks (the first few ms of
+    # launches after idle run ~10 % slower); it precedes the W warm-up steps and is outside the timed region
+    for _ in range(300):
+        model.dev_loglike(B)
+    model.dev_sync()
+    for _ in range(args.warmup):
+        model.dev_loglike(B)
+    model.dev_sync()
+    t0 = time.perf_counter()
+    model.dev_mark(0)                            # HIP event on the stream the kernel is launched on
+    for _ in range(args.steps):
+        model.dev_loglike(B)
+    model.dev_mark(1)
+    model.dev_sync()
+    elapsed = time.perf_counter() - t0
+    out, gpu_logl, kern_s = build_line(args, w, model, B, 1, elapsed, "none", 1, model.dev_mark_elapsed_ms() / args.steps)
+    if not args.no_extras:
+        run_extras(out, model, w, theta, B, not args.no_cpu)
+    if not args.no_cpu:
+        cpu, perr, mean_it = cpu_baseline(w, model.layout, theta, gpu_logl, args.cpu_seconds)
+        out["cpu_baseline"] = cpu
+        out["parity_max_rel_err_vs_oracle"] = perr
+        f_eval = flops_per_eval(len(model.layout.planets), w.table.n_epochs, mean_it)
+        tf = B / kern_s * f_eval / 1e12
+        out["roofline"]["valu_fp64"] = {"achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                        "frac": tf / FP64_VALU_PEAK_TFLOPS, "flops_per_eval": f_eval,
+                                        "mean_newton_steps": mean_it,
+                                        "kepler_solves_per_s": B / kern_s * len(model.layout.planets) * w.table.n_epochs,
+                                        "newton_iterations_per_s": B / kern_s * len(model.layout.planets) * w.table.n_epochs * mean_it}
+    print(json.dumps(out), flush=True)
+
+
+def run_multi(args, w, model, theta, B, rank, world):
+    """N > 1: one rank per GPU.  Order of events, each under the watchdog:
+      1. ranks meet (evidence_amd/rendezvous.py), rank 0's RCCL id goes round, ONE communicator / lane per rank;
+      2. a gathered step is checked (every rank finds its own log-L in its slot, everything finite);
+      3. K steps are timed on one lane (barrier + sync on both sides, max over ranks): a measurement to fall back on;
+      4. the ranks try to add pipeline lanes (ncclCommSplit), agree on the minimum, check a gathered step per lane,
+         and time K steps again — that is the line reported if it completes and verifies, else the one of step 3.
+    If RCCL cannot be initialised on some rank, all ranks gather the downloaded log-L over the rendezvous sockets
+    instead (a slower TRANSPORT, the same kernels) and say so in config.allgather."""
+    from evidence_amd.rendezvous import Rendezvous
+    wd = Watchdog(rank, float(os.environ.get("RVLL_WATCHDOG_S", "90")))
+    with stdout_to_stderr():
+        rdzv = Rendezvous.from_env(timeout=float(os.environ.get("RVLL_RDZV_TIMEOUT_S", "120")))
+    wd.kick("communicator")
+    if rank == 0:
+        wd.hung_line = {"metric": "live_point_logL_evals_per_sec", "value": 0.0, "unit": "evals/s", "n_gpus": world,
+                        "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+                        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                        "config": {"workload": WORKLOAD_TEXT[args.config].format(b=B), "cfg": args.config,
+                                   "parallelism": f"live-point shards x{world}"}}
+    ok, uid = 1, None
+    with stdout_to_stderr():
+        if rank == 0:
+            try:
+                uid = GpuRVModel.comm_unique_id()
+            except Exception as exc:                  # noqa: BLE001 - reported, then the transport falls back
+                print(f"[rank {rank}] RCCL unavailable: {exc}", file=sys.stderr)
+        uid = rdzv.broadcast(uid, src=0)
+        wd.kick()
+        if uid is None:
+            ok = 0
+        else:
+            try:
+                model.comm_init(uid, world, rank)
+            except Exception as exc:                  # noqa: BLE001
+                ok = 0
+                print(f"[rank {rank}] rvll_comm_init failed: {exc}", file=sys.stderr)
+    gather = "rccl" if rdzv.allreduce(ok, "min") == 1 else "host-socket-fallback"
+    if gather != "rccl" and ok:
+        model.comm_destroy()
+    wd.kick("first gathered step")
+    host_all = [None]
+
+    def step():
+        model.dev_loglike(B)
+        if gather == "rccl":
+            model.allgather_logl(B)
+        else:
+            _, mine, _ = model.dev_download(B)
+            host_all[0] = np.concatenate(rdzv.allgather(mine))
+
+    def verified():
+        """After a step: this rank's slot of the gathered vector is its own log-L, and every slot is finite."""
+        model.dev_sync()
+        _, mine, _ = model.dev_download(B)
+        allv = model.download_gathered(world * B) if gather == "rccl" else host_all[0]
+        good = int(np.array_equal(allv[rank * B:(rank + 1) * B], mine) and bool(np.isfinite(allv).all()))
+        return rdzv.allreduce(good, "min") == 1
+
+    def timed(label):
+        wd.kick(f"{label}: warm-up")
+        for i in range(args.warmup):
+            step()
+            if i % 64 == 0:
+                wd.kick()
+        model.dev_sync()
+        rdzv.barrier()
+        model.dev_sync()
+        wd.kick(f"{label}: timed region")
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step()
+            if i % 64 == 0:
+                wd.kick()
+        model.dev_sync()
+        el = time.perf_counter() - t0
+        wd.kick(f"{label}: reduce")
+        rdzv.barrier()
+        return rdzv.allreduce(el, "max")
+
+    for _ in range(300):                             # untimed pre-warm (clocks), as in the N = 1 run
+        model.dev_loglike(B)
+    model.dev_sync()
+    step()
+    if not verified():
+        raise SystemExit(f"[rank {rank}] bench.py: the gathered log-L does not match the ranks' own values")
+    elapsed, lanes = timed("one lane"), 1
+    single = None
+    if rank == 0:
+        single, _, _ = build_line(args, w, model, B, world, elapsed, gather, 1, None)
+        wd.fallback_line = single
+    want = int(os.environ.get("RVLL_LANES", "3"))
+    if gather == "rccl" and want > 1:
+        wd.kick("adding pipeline lanes")
+        with stdout_to_stderr():
+            have = model.comm_add_lanes(want)
+        agreed = rdzv.allreduce(have, "min")          # every rank must cycle through the same communicators
+        if agreed > 1:
+            model.comm_set_lanes(agreed)
+            wd.kick("first gathered steps on every lane")
+            good = True
+            for _ in range(agreed):                   # one gathered step per lane, each checked
+                step()
+                good = verified() and good
+            if good:
+                el2 = timed(f"{agreed} lanes")
+                for _ in range(agreed):
+                    step()
+                if verified():
+                    elapsed, lanes = el2, agreed
+            if lanes == 1:
+                model.comm_set_lanes(1)
+    wd.kick("report")
+    if rank == 0:
+        out, _, _ = build_line(args, w, model, B, world, elapsed, gather, lanes, None)
+        if lanes > 1:
+            out["single_lane_evals_per_s"] = single["value"]
+        print(json.dumps(out), flush=True)
+    rdzv.barrier()
+    wd.stop()
+    if gather == "rccl":
+        model.comm_destroy()
+    rdzv.close()
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -307,12 +569,6 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
 
-    dist = None
-    if world > 1:
-        import torch.distributed as dist      # control plane only: barrier, max-reduce, id exchange
-        with stdout_to_stderr():              # gloo announces its connections on stdout
-            dist.init_process_group("gloo")
-
     w = make_workload(args.config)
     B = args.batch or (CONFIGS[args.config]["batch"] // (8 if args.config in (4, 5) else 1))
     theta = w.sample_theta(B, seed=1234 + rank)
@@ -321,145 +577,16 @@ def main():
         sys.exit("bench.py: no HIP device visible; evidence_amd has no CPU path")
     if local_rank >= ndev:
         print(f"[rank {rank}] only {ndev} device(s) visible: sharing device {local_rank % ndev} "
-              f"(rehearsal only - RCCL refuses two ranks on one GPU and the gloo transport is used)", file=sys.stderr)
+              f"(rehearsal only - RCCL refuses two ranks on one GPU and the socket transport is used)", file=sys.stderr)
     model = GpuRVModel(w.fixedpardict, w.table, w.parnames, device=local_rank % ndev, precision=args.precision)
     if args.points_per_block:
         model.set_points_per_block(args.points_per_block)
     model.dev_upload_theta(theta)                # inputs resident in HBM before the timed region
-
-    gather = "none"
-    if world > 1:
-        import torch
-        # RCCL communicator over the GPUs of this node: rank 0 creates the 128-byte id, the launcher's
-        # store carries it.  Every rank reports whether its init worked; if ANY failed, all ranks fall
-        # back to gathering the downloaded log-L over gloo (a slower TRANSPORT, same kernel), so the run
-        # still completes and says so in `config.allgather`.
-        ok, stuck = 1, False
-        ids = [None]
-        with stdout_to_stderr():
-            if rank == 0:
-                uid, err = call_with_timeout(GpuRVModel.comm_unique_id, 120.0)
-                if err is not None:
-                    ok, stuck = 0, isinstance(err, TimeoutError)
-                    print(f"[rank {rank}] RCCL unavailable: {err}", file=sys.stderr)
-                ids = [uid]
-            dist.broadcast_object_list(ids, src=0)
-            if ok and ids[0] is not None:
-                _, err = call_with_timeout(lambda: model.comm_init(ids[0], world, rank), 180.0)
-                if err is not None:
-                    ok, stuck = 0, stuck or isinstance(err, TimeoutError)
-                    print(f"[rank {rank}] rvll_comm_init failed: {err}", file=sys.stderr)
-            else:
-                ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        gather = "rccl" if int(flag.item()) == 1 else "gloo-host-fallback"
-        if gather != "rccl":
-            host_parts = [torch.empty(B, dtype=torch.float64) for _ in range(world)]
-
-    def step():
-        model.dev_loglike(B)
-        if gather == "rccl":
-            model.allgather_logl(B)
-        elif gather == "gloo-host-fallback":
-            _, mine, _ = model.dev_download(B)
-            dist.all_gather(host_parts, torch.from_numpy(mine))
-
-    # untimed pre-warm so that a short --warmup still starts from ramped clocks (the first few ms of
-    # launches after idle run ~10 % slower); it precedes the W warm-up steps and is outside the timed region
-    for _ in range(300):
-        model.dev_loglike(B)
-    model.dev_sync()
-    for _ in range(args.warmup):
-        step()
-    model.dev_sync()
-    if dist:
-        dist.barrier()
-    model.dev_sync()
-    t0 = time.perf_counter()
     if world == 1:
-        model.dev_mark(0)                        # HIP event on the stream the kernel is launched on
-    for _ in range(args.steps):
-        step()
-    if world == 1:
-        model.dev_mark(1)
-    model.dev_sync()
-    elapsed = time.perf_counter() - t0
-    timed_region_kernel_ms = model.dev_mark_elapsed_ms() / args.steps if world == 1 else None
-    if dist:
-        dist.barrier()
-        tmax = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-
-    if world > 1:                                # every rank holds all N*B log-L values
-        _, mine, _ = model.dev_download(B)
-        allv = (model.download_gathered(world * B) if gather == "rccl"
-                else np.concatenate([p.numpy() for p in host_parts]))
-        assert np.array_equal(allv[rank * B:(rank + 1) * B], mine), "all-gather slot mismatch"
-
-    if rank == 0:
-        value = world * B * args.steps / elapsed
-        # dominant kernel, measured live with HIP events on the stream it is launched on
-        tm = model.dev_time_loglike(B, warmup=max(3, args.warmup // 4), iters=max(10, min(args.steps, 200)))
-        _, gpu_logl, flags = model.dev_download(B, flags=True)
-        # the roofline uses the launch duration over the TIMED REGION itself (HIP events around its K launches on
-        # their stream); the per-launch statistics of a separate event-per-launch run are reported beside it
-        kern_s = (timed_region_kernel_ms if timed_region_kernel_ms is not None else tm["kernel_ms_mean"]) * 1e-3
-        abytes = algorithmic_bytes_per_launch(w.ndim, w.table.n_epochs, B)
-        achieved = abytes / kern_s / 1e9
-        out = {
-            "metric": "live_point_logL_evals_per_sec", "value": value, "unit": "evals/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {"fp64": "f64", "mixed": "f32 Newton / f64 phase+chi2 (NOT a parity mode)",
-                                             "fp32": "f32 / f64 phase+sum (NOT a parity mode)"}[args.precision],
-            "data": "synthetic",
-            "config": {"workload": WORKLOAD_TEXT[args.config].format(b=B), "cfg": args.config,
-                       "live_points_per_gpu": B, "epochs": w.table.n_epochs, "planets": len(model.layout.planets),
-                       "instruments": len(w.table.insts), "free_parameters": w.ndim,
-                       "parallelism": f"live-point shards x{world}", "allgather": gather,
-                       "step_structure": ("one stream: launch k+1 starts when launch k has drained (value == B / kernel time)"
-                                          if world == 1 else
-                                          "two pipeline lanes (stream + communicator + buffers each): kernel ; all-gather "
-                                          "in-stream, consecutive steps alternate lanes, so two launches are in flight; "
-                                          "the N=1 equivalent is two_lane_pipelined_evals_per_s of the N=1 line")},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.config, B),
-                         "kernel": "loglike_kernel",
-                         "kernel_ms_timed_region": kern_s * 1e3,     # what `achieved` is computed from
-                         "kernel_ms_mean": tm["kernel_ms_mean"],      # event-per-launch statistics (separate run)
-                         "kernel_ms_min": tm["kernel_ms_min"], "kernel_ms_median": tm["kernel_ms_median"],
-                         "algorithmic_bytes_per_launch": abytes,
-                         "points_per_block": tm["points_per_block"], "blocks": tm["blocks"],
-                         "kernel_evals_per_s": B / kern_s,
-                         "note": "fused kernel is fp64-VALU bound, not HBM bound (DESIGN.md); see valu_fp64"},
-        }
-        if world == 1 and not args.no_extras:
-            run_extras(out, model, w, theta, B, not args.no_cpu)
-        if not args.no_cpu and world == 1:
-            cpu, perr, mean_it = cpu_baseline(w, model.layout, theta, gpu_logl, args.cpu_seconds)
-            out["cpu_baseline"] = cpu
-            out["parity_max_rel_err_vs_oracle"] = perr
-            f_eval = flops_per_eval(len(model.layout.planets), w.table.n_epochs, mean_it)
-            tf = B / kern_s * f_eval / 1e12
-            out["roofline"]["valu_fp64"] = {"achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                            "frac": tf / FP64_VALU_PEAK_TFLOPS, "flops_per_eval": f_eval,
-                                            "mean_newton_steps": mean_it,
-                                            "kepler_solves_per_s": B / kern_s * len(model.layout.planets) * w.table.n_epochs,
-                                            "newton_iterations_per_s": B / kern_s * len(model.layout.planets) * w.table.n_epochs * mean_it}
-        print(json.dumps(out), flush=True)
-
-    if gather == "rccl":
-        model.comm_destroy()
-    if dist:
-        dist.barrier()
-    if world > 1 and stuck:
-        sys.stdout.flush()
-        os._exit(0)          # a thread is still blocked inside the RCCL bootstrap: do not wait for it
+        run_single(args, w, model, theta, B)
+    else:
+        run_multi(args, w, model, theta, B, rank, world)
     model.close()
-    if dist:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

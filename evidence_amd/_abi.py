@@ -96,7 +96,7 @@ PROTOTYPES = {
     "rvll_set_priors": (C.c_int, [Handle, C.POINTER(Prior), C.c_int32]),
     "rvll_prior_table_info": (C.c_int, [Handle, C.c_int32, _dp, _ip]),
     "rvll_slice_walk": (C.c_int, [Handle, _dp, _dp, _dp, C.c_int64, C.c_double, _dp, _ip, C.c_int32, C.c_int32,
-                                  C.c_uint64, C.POINTER(C.c_int64)]),
+                                  C.c_uint64, C.c_int64, C.POINTER(C.c_int64)]),
     "rvll_scalar_server": (C.c_int, [Handle, C.c_int32]),
     "rvll_loglike_batch": (C.c_int, [Handle, _dp, C.c_int64, _dp, _ip]),
     "rvll_prior_batch": (C.c_int, [Handle, _dp, C.c_int64, _dp]),
@@ -119,6 +119,10 @@ PROTOTYPES = {
     "rvll_set_slim_table_range": (C.c_int, [Handle, C.c_double]),
     "rvll_comm_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
     "rvll_comm_init": (C.c_int, [Handle, C.POINTER(C.c_ubyte), C.c_int32, C.c_int32]),
+    "rvll_comm_add_lanes": (C.c_int, [Handle, C.c_int32, _ip]),
+    "rvll_comm_set_lanes": (C.c_int, [Handle, C.c_int32]),
+    "rvll_allgather_host": (C.c_int, [Handle, _dp, C.c_int64, _dp]),
+    "rvll_runtime_info": (C.c_int, [C.c_char_p, C.c_int32]),
     "rvll_allgather_logl": (C.c_int, [Handle, C.c_int64]),
     "rvll_download_gathered": (C.c_int, [Handle, C.c_int64, _dp]),
     "rvll_allgather_theta": (C.c_int, [Handle, C.c_int64]),

@@ -85,13 +85,40 @@ constexpr int kNcclFloat64 = 8;   // ncclDouble / ncclFloat64 in rccl.h
 
 Rccl g_rccl;
 
+std::string g_rccl_path;      // where the loaded librccl lives (dladdr)
+int g_rccl_version = 0;       // ncclGetVersion
+
+std::string lib_path_of(const void* symbol)
+{
+    Dl_info info;
+    return (symbol && dladdr(symbol, &info) && info.dli_fname) ? std::string(info.dli_fname) : std::string("?");
+}
+
+// Which librccl: the one next to the HIP runtime this library is linked against — the ROCm it was built and tested
+// with — not whatever a soname lookup finds first (a process that imported torch first would get torch's bundled
+// RCCL and HIP runtime).  Order: RVLL_RCCL_PATH, the directory of the loaded libamdhip64, /opt/rocm/lib, sonames.
 int rccl_load()
 {
     if (g_rccl.lib) return RVLL_OK;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    std::vector<std::string> names;
+    if (const char* e = getenv("RVLL_RCCL_PATH")) names.push_back(e);
+    const std::string hip = lib_path_of(reinterpret_cast<const void*>(&hipGetDeviceCount));
+    const size_t slash = hip.rfind('/');
+    if (slash != std::string::npos) {
+        names.push_back(hip.substr(0, slash) + "/librccl.so.1");
+        names.push_back(hip.substr(0, slash) + "/librccl.so");
+    }
+    names.push_back("/opt/rocm/lib/librccl.so.1");
+    names.push_back("librccl.so.1");
+    names.push_back("librccl.so");
     void* lib = nullptr;
-    for (const char* n : names) { lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
-    if (!lib) return fail(RVLL_E_RCCL, "cannot dlopen librccl: %s", dlerror());
+    std::string tried;
+    for (const std::string& n : names) {
+        lib = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (lib) break;
+        tried += n + " ";
+    }
+    if (!lib) return fail(RVLL_E_RCCL, "cannot dlopen librccl (tried %s): %s", tried.c_str(), dlerror());
     Rccl r;
     r.lib = lib;
     r.GetUniqueId    = (int (*)(void*))dlsym(lib, "ncclGetUniqueId");
@@ -105,6 +132,8 @@ int rccl_load()
         return fail(RVLL_E_RCCL, "librccl lacks an expected nccl* symbol");
     }
     g_rccl = r;
+    g_rccl_path = lib_path_of(reinterpret_cast<const void*>(r.AllGather));
+    if (auto ver = (int (*)(int*))dlsym(lib, "ncclGetVersion")) (void)ver(&g_rccl_version);
     return RVLL_OK;
 }
 
@@ -1331,7 +1360,7 @@ int rvll_prior_loglike_batch(rvll_handle* h, const double* cube, int64_t B,
 // ---- device-resident slice-sampling walk ---------------------------------------------------------------
 int rvll_slice_walk(rvll_handle* h, double* cube, double* theta, double* logl, int64_t K, double lstar,
                     const double* chol, const int32_t* wrapped, int32_t nsteps, int32_t max_rounds,
-                    uint64_t seed, int64_t* ncalls)
+                    uint64_t seed, int64_t walker_base, int64_t* ncalls)
 {
     int rc = use_device(h);
     if (rc) return rc;
@@ -1340,8 +1369,9 @@ int rvll_slice_walk(rvll_handle* h, double* cube, double* theta, double* logl, i
     if (ncalls) *ncalls = 0;
     if (K == 0 || nsteps == 0) return RVLL_OK;
     if (!cube || !theta || !logl || !chol) return fail(RVLL_E_INVALID, "null buffer");
-    if (max_rounds < 1 || max_rounds > 4096 || nsteps >= (1 << 18) || K >= (1LL << 31))
-        return fail(RVLL_E_INVALID, "nsteps / max_rounds / K out of range");
+    if (max_rounds < 1 || max_rounds > 4096 || nsteps >= (1 << 18) || K >= (1LL << 31) || walker_base < 0 ||
+        walker_base + K >= (1LL << 32))
+        return fail(RVLL_E_INVALID, "nsteps / max_rounds / K / walker_base out of range");
     const size_t D = (size_t)h->L.ndim;
     if (D < 1) return fail(RVLL_E_INVALID, "no free parameter to walk in");
     rc = rvll_dev_reserve(h, K);                       // scratch rows: d_cube, d_theta, log-L / flags of lane 0
@@ -1401,7 +1431,7 @@ int rvll_slice_walk(rvll_handle* h, double* cube, double* theta, double* logl, i
     const bool slim = h->all_direct && !getenv("RVLL_WALK_FAT");
     rvll::WalkArgs w{h->d_walk_u, h->d_walk_theta, h->d_walk_logl, h->d_walk_chol, h->d_walk_wrapped, (long long)K,
                      nsteps, max_rounds, (unsigned long long)seed, lstar, h->d_walk_ncalls,
-                     h->d_walk_steps, nullptr, nullptr};
+                     h->d_walk_steps, nullptr, nullptr, (long long)walker_base};
     HIP_TRY(rvll::launch_slice_walk(a, w, !slim, st));
     unsigned long long n = 0;
     std::vector<int32_t> steps(slim ? (size_t)K : 0);
@@ -1531,6 +1561,23 @@ int rvll_comm_unique_id(unsigned char id[RVLL_COMM_ID_BYTES])
     return RVLL_OK;
 }
 
+int rvll_runtime_info(char* buf, int32_t buflen)
+{
+    if (!buf || buflen < 1) return fail(RVLL_E_INVALID, "bad buffer");
+    int hip_rt = 0, hip_drv = 0;
+    (void)hipRuntimeGetVersion(&hip_rt);
+    (void)hipDriverGetVersion(&hip_drv);
+    snprintf(buf, (size_t)buflen,
+             "{\"hip_runtime_version\": %d, \"hip_driver_version\": %d, \"libamdhip64\": \"%s\", "
+             "\"librccl\": \"%s\", \"rccl_version\": %d, \"librvll\": \"%s\"}",
+             hip_rt, hip_drv, lib_path_of(reinterpret_cast<const void*>(&hipGetDeviceCount)).c_str(),
+             g_rccl.lib ? g_rccl_path.c_str() : "not loaded", g_rccl_version,
+             lib_path_of(reinterpret_cast<const void*>(&rvll_runtime_info)).c_str());
+    return RVLL_OK;
+}
+
+// One communicator, one pipeline lane: the gather of a step runs in-stream behind its kernel.  Further lanes are
+// added by rvll_comm_add_lanes once the caller has seen a gathered step complete on this one.
 int rvll_comm_init(rvll_handle* h, const unsigned char id[RVLL_COMM_ID_BYTES], int32_t nranks, int32_t rank)
 {
     int rc = use_device(h);
@@ -1546,20 +1593,52 @@ int rvll_comm_init(rvll_handle* h, const unsigned char id[RVLL_COMM_ID_BYTES], i
     h->nranks = nranks;
     h->rank = rank;
     h->nlanes = 1;
-    // further pipeline lanes: one communicator each (collectives of ONE communicator must not run concurrently
-    // on two streams), derived collectively from the first — no further id exchange.  Without ncclCommSplit
-    // the step degrades to one lane: the gather then runs in-stream behind its kernel, still correct.
-    int want = 3;                                             // two kernels stay in flight while one lane gathers
-    if (const char* e = getenv("RVLL_LANES")) want = std::max(1, std::min(kMaxLanes, atoi(e)));
-    if (getenv("RVLL_SINGLE_LANE")) want = 1;                 // test switch for the degraded path
-    for (int l = 1; l < want; ++l) {
-        if (!g_rccl.CommSplit || g_rccl.CommSplit(h->nccl_comm[0], 0, rank, &h->nccl_comm[l], nullptr) != 0 || !h->nccl_comm[l]) {
+    h->logl_cur = 0;
+    return RVLL_OK;
+}
+
+// Further pipeline lanes: one communicator each (collectives of ONE communicator must not run concurrently on two
+// streams), derived collectively from the first by ncclCommSplit — every rank must make this call.  Returns in
+// *have how many lanes THIS rank now holds (<= want); the ranks must then agree on the minimum over all of them
+// (out of band) and call rvll_comm_set_lanes with it, so that every rank cycles through the same communicators:
+// a rank with fewer lanes than its peers would issue its gathers on mismatched communicators and hang them all.
+int rvll_comm_add_lanes(rvll_handle* h, int32_t want, int32_t* have)
+{
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!h->nccl_comm[0]) return fail(RVLL_E_RCCL, "rvll_comm_init has not been called");
+    want = std::max(1, std::min(kMaxLanes, (int)want));
+    int got = 1;
+    for (int l = 1; l < kMaxLanes; ++l) if (h->nccl_comm[l]) got = l + 1; else break;
+    for (int l = got; l < want; ++l) {
+        if (!g_rccl.CommSplit || g_rccl.CommSplit(h->nccl_comm[0], 0, h->rank, &h->nccl_comm[l], nullptr) != 0 || !h->nccl_comm[l]) {
             h->nccl_comm[l] = nullptr;
             break;
         }
-        h->nlanes = l + 1;
+        got = l + 1;
     }
+    if (have) *have = got;
+    return RVLL_OK;
+}
+
+int rvll_comm_set_lanes(rvll_handle* h, int32_t nlanes)
+{
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!h->nccl_comm[0]) return fail(RVLL_E_RCCL, "rvll_comm_init has not been called");
+    if (nlanes < 1 || nlanes > kMaxLanes) return fail(RVLL_E_INVALID, "nlanes out of range");
+    for (int l = 0; l < nlanes; ++l)
+        if (!h->nccl_comm[l]) return fail(RVLL_E_INVALID, "lane %d has no communicator on this rank", l);
+    HIP_TRY(hipStreamSynchronize(h->compute));
+    rc = sync_other_lanes(h);
+    if (rc) return rc;
+    if (nlanes > h->nlanes && h->gather_cap > 0) {          // gather buffers of the new lanes
+        for (int l = h->nlanes; l < nlanes; ++l)
+            if (!h->d_gather2[l]) HIP_TRY(hipMalloc(&h->d_gather2[l], sizeof(double) * (size_t)h->gather_cap));
+    }
+    h->nlanes = nlanes;
     h->logl_cur = 0;
+    if (nlanes == 1 && h->pipelined) { h->pipelined = false; h->geo.clear(); }
     return RVLL_OK;
 }
 
@@ -1616,6 +1695,33 @@ int rvll_allgather_theta(rvll_handle* h, int64_t B_local)
     RCCL_TRY(g_rccl.AllGather(h->d_theta, h->d_gather_theta, (size_t)B_local * D, kNcclFloat64,
                               h->nccl_comm[0], h->compute));
     return RVLL_OK;
+}
+
+// All-gather of a small host buffer (the sampler's sharded host state: walk end points, call counts): n_local
+// doubles per rank go up, are gathered on the device by RCCL on lane 0's communicator and stream, and nranks *
+// n_local come back, rank-major.  Synchronous.
+int rvll_allgather_host(rvll_handle* h, const double* mine, int64_t n_local, double* all)
+{
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!h->nccl_comm[0]) return fail(RVLL_E_RCCL, "rvll_comm_init has not been called");
+    if (!mine || !all || n_local < 1) return fail(RVLL_E_INVALID, "bad allgather_host arguments");
+    const size_t total = (size_t)n_local * (size_t)h->nranks;
+    double *d_in = nullptr, *d_out = nullptr;
+    HIP_TRY(hipMalloc(&d_in, sizeof(double) * (size_t)n_local));
+    hipError_t e = hipMalloc(&d_out, sizeof(double) * total);
+    int status = RVLL_OK;
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in, mine, sizeof(double) * (size_t)n_local, hipMemcpyHostToDevice, h->compute);
+    if (e == hipSuccess) {
+        const int r = g_rccl.AllGather(d_in, d_out, (size_t)n_local, kNcclFloat64, h->nccl_comm[0], h->compute);
+        if (r != 0) status = fail(RVLL_E_RCCL, "ncclAllGather failed: %s", g_rccl.GetErrorString(r));
+    }
+    if (status == RVLL_OK && e == hipSuccess) e = hipMemcpyAsync(all, d_out, sizeof(double) * total, hipMemcpyDeviceToHost, h->compute);
+    if (status == RVLL_OK && e == hipSuccess) e = hipStreamSynchronize(h->compute);
+    if (status == RVLL_OK && e != hipSuccess) status = fail(RVLL_E_HIP, "allgather_host: %s", hipGetErrorString(e));
+    (void)hipStreamSynchronize(h->compute);
+    dev_free(d_in); dev_free(d_out);
+    return status;
 }
 
 int rvll_download_gathered_theta(rvll_handle* h, int64_t B_total, double* theta_all)

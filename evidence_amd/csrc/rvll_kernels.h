@@ -95,6 +95,8 @@ struct WalkArgs {
                                //          deferred and stopped at the start of that move)
     const int32_t* walker_id;  // [K] or null: the walker's index in the random-number counters (default: its row)
     const int32_t* step_start; // [K] or null: move to resume at (default 0)
+    long long walker_base;     // added to the row (or to walker_id) in the random-number counters: a shard of a larger
+                               // set of walkers draws exactly what the unsharded walk would draw for its rows
 };
 size_t walk_lds_bytes(const LoglikeArgs& a);
 // a: fused (cube -> theta -> log-L) arguments whose cube / theta_out / logL / flags rows [0, K) are scratch

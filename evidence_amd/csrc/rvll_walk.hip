@@ -72,7 +72,7 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
         for (int i = tid; i < nact * D; i += kThreads) {
             const int pl = act[i / D], k = i % D;
             if (state[pl] != 0) continue;
-            const unsigned long long wid = w.walker_id ? (unsigned long long)w.walker_id[w0 + pl] : (unsigned long long)(w0 + pl);
+            const unsigned long long wid = (unsigned long long)(w.walker_base + (w.walker_id ? (long long)w.walker_id[w0 + pl] : w0 + pl));
             const unsigned long long ctr = (wid << 32) | ((unsigned long long)step_of[pl] << 14) | (unsigned)(2 * k);
             const double u1 = uniform01(w.seed, ctr), u2 = uniform01(w.seed, ctr + 1);
             double sn, cs;
@@ -121,7 +121,7 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
                 round_of[pl] = 0;
                 state[pl] = 1;
             }
-            const unsigned long long wid = w.walker_id ? (unsigned long long)w.walker_id[w0 + pl] : (unsigned long long)(w0 + pl);
+            const unsigned long long wid = (unsigned long long)(w.walker_base + (w.walker_id ? (long long)w.walker_id[w0 + pl] : w0 + pl));
             const unsigned long long ctr = (wid << 32) | ((unsigned long long)step_of[pl] << 14) | (unsigned)(8192 + round_of[pl]);
             tcur[pl] = tmin[pl] + (tmax[pl] - tmin[pl]) * uniform01(w.seed, ctr);
         }

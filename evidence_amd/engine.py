@@ -221,10 +221,13 @@ class GpuRVModel:
     def dev_loglike(self, n):
         _abi.check(self._lib.rvll_dev_loglike(self._h, int(n)))
 
-    def slice_walk(self, cube, theta, logl, lstar, chol, wrapped=None, nsteps=10, max_rounds=200, seed=0):
+    def slice_walk(self, cube, theta, logl, lstar, chol, wrapped=None, nsteps=10, max_rounds=200, seed=0,
+                   walker_base=0):
         """nsteps slice-sampling moves of every walker inside logL > lstar, entirely on the GPU
         (rvll_slice_walk).  cube/theta/logl are the walkers' start points; returns (cube, theta, logl, ncalls)
-        of the end points.  chol: lower-triangular factor of the live points' covariance in the unit cube."""
+        of the end points.  chol: lower-triangular factor of the live points' covariance in the unit cube.
+        walker_base: index of the first row in a larger set of walkers (sharded walks draw the same random numbers
+        as the unsharded one)."""
         cube = np.array(self._theta2d(cube), dtype=np.float64, order="C")
         theta = np.array(self._theta2d(theta), dtype=np.float64, order="C")
         logl = np.array(logl, dtype=np.float64).reshape(-1)
@@ -239,7 +242,7 @@ class GpuRVModel:
         _abi.check(self._lib.rvll_slice_walk(
             self._h, _abi.as_dp(cube), _abi.as_dp(theta), _abi.as_dp(logl), k, float(lstar), _abi.as_dp(chol),
             _abi.as_ip(wr) if wr is not None else None, int(nsteps), int(max_rounds), int(seed) & (2 ** 64 - 1),
-            C.byref(ncalls)))
+            int(walker_base), C.byref(ncalls)))
         return cube, theta, logl, int(ncalls.value)
 
     def scalar_server(self, enable=True):
@@ -336,6 +339,31 @@ class GpuRVModel:
             raise ValueError("comm id must be 128 bytes")
         buf = (C.c_ubyte * _abi.COMM_ID_BYTES).from_buffer_copy(comm_id)
         _abi.check(self._lib.rvll_comm_init(self._h, buf, int(nranks), int(rank)))
+
+    def comm_add_lanes(self, want=3):
+        """Collective: try to add pipeline lanes (ncclCommSplit); returns how many this rank holds.  The ranks must
+        agree on the minimum and call comm_set_lanes with it (include/rvll.h)."""
+        have = C.c_int32(1)
+        _abi.check(self._lib.rvll_comm_add_lanes(self._h, int(want), C.byref(have)))
+        return have.value
+
+    def comm_set_lanes(self, n):
+        _abi.check(self._lib.rvll_comm_set_lanes(self._h, int(n)))
+
+    def allgather_host(self, mine, world):
+        """RCCL all-gather of a small float64 host array: [n] per rank -> [world, n] on every rank."""
+        mine = np.ascontiguousarray(mine, dtype=np.float64).ravel()
+        out = np.empty((int(world), mine.size), dtype=np.float64)
+        _abi.check(self._lib.rvll_allgather_host(self._h, _abi.as_dp(mine), mine.size, _abi.as_dp(out)))
+        return out
+
+    @staticmethod
+    def runtime_info():
+        """Which HIP runtime / RCCL / librvll this process runs on (include/rvll.h rvll_runtime_info)."""
+        import json
+        buf = C.create_string_buffer(2048)
+        _abi.check(_abi.load().rvll_runtime_info(buf, len(buf)))
+        return json.loads(buf.value.decode())
 
     def allgather_logl(self, n_local):
         _abi.check(self._lib.rvll_allgather_logl(self._h, int(n_local)))

@@ -15,6 +15,8 @@ from typing import Callable, Optional
 
 import numpy as np
 
+from .settings import ultranest_defaults
+
 
 @dataclass
 class NestedResult:
@@ -51,7 +53,7 @@ class _Ellipsoid:
         return self.mean + self.radius * (z @ self.chol.T)
 
 
-def run_nested(prior: Callable, loglike: Callable, ndim: int, nlive: int = 400, dlogz: float = 0.5,
+def run_nested(prior: Callable, loglike: Callable, ndim: int, nlive: Optional[int] = None, dlogz: float = 0.5,
                max_iter: int = 200000, max_calls: int = 5_000_000, batch: int = 1024, enlarge: float = 1.25, update_every: Optional[int] = None,
                seed: int = 0) -> NestedResult:
     """Nested sampling with vectorized callbacks.  Stops when the live points can add less than
@@ -59,6 +61,7 @@ def run_nested(prior: Callable, loglike: Callable, ndim: int, nlive: int = 400, 
     or — so that a collapsing acceptance rate can never spin forever — once `max_calls` likelihood
     evaluations have been spent (the result then covers the iterations completed so far)."""
     rng = np.random.default_rng(seed)
+    nlive = int(nlive or ultranest_defaults(ndim)["nlive"])          # the reference's default: 25 ndim
     u = rng.random((nlive, ndim))
     theta = np.asarray(prior(u), dtype=np.float64)
     logl = np.asarray(loglike(theta), dtype=np.float64)
@@ -143,7 +146,7 @@ def _chord(u, d, wrapped):
     return lo.max(axis=1), hi.min(axis=1)
 
 
-def run_nested_slice(prior: Callable, loglike: Callable, ndim: int, nlive: int = 400, kbatch: Optional[int] = None,
+def run_nested_slice(prior: Callable, loglike: Callable, ndim: int, nlive: Optional[int] = None, kbatch: Optional[int] = None,
                      nsteps: Optional[int] = None, dlogz: float = 0.5, max_iter: int = 10_000_000,
                      max_calls: int = 50_000_000, wrapped=None, seed: int = 0,
                      prior_loglike: Optional[Callable] = None, walker: Optional[Callable] = None) -> NestedResult:
@@ -162,13 +165,15 @@ def run_nested_slice(prior: Callable, loglike: Callable, ndim: int, nlive: int =
     chord inside the unit cube (circular `wrapped` parameters wrap instead) and is shrunk towards the
     current position until a proposal is accepted.  Every shrink round evaluates ALL unfinished walkers in
     one vectorized callback call — one prior + log-L launch on the GPU.  Defaults follow the reference's
-    UltraNest wrapper: nsteps = 3 ndim... see evidence/ultranest/__init__.py:333-338 (nsteps) and :159-163
-    (wrapped parameters)."""
+    UltraNest wrapper (evidence_amd/settings.py: nlive = 25 ndim, nsteps = 3 ndim, dlogz = 0.5;
+    evidence/ultranest/__init__.py:333-338) and :159-163 (wrapped parameters)."""
     rng = np.random.default_rng(seed)
+    defaults = ultranest_defaults(ndim)
+    nlive = int(nlive or defaults["nlive"])
     kbatch = int(kbatch or max(1, nlive // 4))
     if not 1 <= kbatch < nlive:
         raise ValueError("need 1 <= kbatch < nlive")
-    nsteps = int(nsteps or 3 * ndim)
+    nsteps = int(nsteps or defaults["nsteps"])
     wrapped = None if wrapped is None else np.asarray(wrapped, dtype=bool)
     u = rng.random((nlive, ndim))
     theta = np.asarray(prior(u), dtype=np.float64)

@@ -5,11 +5,12 @@ samplers (evidence/polychord/__init__.py:21-29,176-199; evidence/ultranest/__ini
 there is no other exchange on this path, so there is no other collective — except that when theta itself was
 produced on the device from a cube shard (ShardedPriorLogLike), its rows travel back the same way.
 
-Two transports for the same partition:
+Three transports for the same partition:
   "rccl"  the device buffer the log-L kernel wrote is all-gathered in place by RCCL over xGMI on the
-          handle's comm stream (rvll_allgather_logl) — the product path on a GPU node;
-  "dist"  torch.distributed all_gather of host buffers (gloo) — used by the CPU tests of the sharding
-          logic, and as a transport fallback if RCCL cannot be initialised.
+          handle's stream (rvll_allgather_logl; host-side rows: rvll_allgather_host) — the product path on a GPU node;
+  "rdzv"  host buffers over evidence_amd/rendezvous.py (plain sockets, no torch) — the fallback transport if RCCL
+          cannot be initialised, and what a launcher-less script can use;
+  "dist"  torch.distributed all_gather of host buffers (gloo) — used by the CPU tests of the sharding logic.
 The evaluation itself is always whatever `evaluate` is: GpuRVModel.log_likelihood_batch in the product.
 """
 from typing import Callable, List, Tuple
@@ -35,6 +36,29 @@ def padded_count(n_points: int, world: int) -> int:
     return -(-n_points // world) if n_points else 0
 
 
+def gather_rows(mine: np.ndarray, world: int, transport: str, model=None, group=None) -> np.ndarray:
+    """All-gather of equally shaped float64 host arrays: -> [world, *mine.shape] on every rank."""
+    mine = np.ascontiguousarray(mine, dtype=np.float64)
+    if transport == "rccl":
+        return model.allgather_host(mine.ravel(), world).reshape((world,) + mine.shape)
+    if transport == "rdzv":
+        return np.stack(group.allgather(mine))
+    import torch
+    import torch.distributed as dist
+    parts = [torch.empty(mine.shape, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(parts, torch.from_numpy(mine.copy()))
+    return torch.stack(parts).numpy()
+
+
+def _check_transport(transport, model, group):
+    if transport not in ("dist", "rccl", "rdzv"):
+        raise ValueError(transport)
+    if transport == "rccl" and model is None:
+        raise ValueError("the rccl transport gathers through the model's communicator: pass model=")
+    if transport == "rdzv" and group is None:
+        raise ValueError("the rdzv transport needs group= (an evidence_amd.rendezvous.Rendezvous)")
+
+
 def unpad(gathered: np.ndarray, n_points: int, world: int) -> np.ndarray:
     """[world * padded] rank-major -> [n_points] in original row order."""
     pad = padded_count(n_points, world)
@@ -48,14 +72,11 @@ class ShardedLogLike:
     one all-gather.  Returns the full [n] log-L vector on every rank."""
 
     def __init__(self, rank: int, world: int, evaluate: Callable[[np.ndarray], np.ndarray] = None,
-                 model=None, transport: str = "dist"):
-        if transport not in ("dist", "rccl"):
-            raise ValueError(transport)
-        if transport == "rccl" and model is None:
-            raise ValueError("the rccl transport gathers the model's device buffer: pass model=")
+                 model=None, transport: str = "dist", group=None):
+        _check_transport(transport, model, group)
         if evaluate is None and model is None:
             raise ValueError("pass evaluate= or model=")
-        self.rank, self.world, self.model, self.transport = rank, world, model, transport
+        self.rank, self.world, self.model, self.transport, self.group = rank, world, model, transport, group
         self.evaluate = evaluate if evaluate is not None else model.log_likelihood_batch
 
     def __call__(self, theta: np.ndarray) -> np.ndarray:
@@ -76,14 +97,10 @@ class ShardedLogLike:
             m.dev_loglike(pad)
             m.allgather_logl(pad)
             return unpad(m.download_gathered(self.world * pad), n, self.world)
-        import torch
-        import torch.distributed as dist
-        mine = torch.zeros(pad, dtype=torch.float64)
+        mine = np.zeros(pad)
         if hi > lo:
-            mine[: hi - lo] = torch.from_numpy(np.asarray(self.evaluate(shard), dtype=np.float64))
-        parts = [torch.empty(pad, dtype=torch.float64) for _ in range(self.world)]
-        dist.all_gather(parts, mine)
-        return unpad(torch.cat(parts).numpy(), n, self.world)
+            mine[: hi - lo] = np.asarray(self.evaluate(shard), dtype=np.float64)
+        return unpad(gather_rows(mine, self.world, self.transport, group=self.group).ravel(), n, self.world)
 
 
 class ShardedPriorLogLike:
@@ -93,14 +110,12 @@ class ShardedPriorLogLike:
     Returns (theta [n, ndim], logL [n]) on every rank.  Transports as in ShardedLogLike; with "dist" the
     evaluation is `evaluate(cubes) -> (theta, logL)` (GpuRVModel.prior_loglike_batch in the product)."""
 
-    def __init__(self, rank: int, world: int, evaluate: Callable = None, model=None, transport: str = "dist"):
-        if transport not in ("dist", "rccl"):
-            raise ValueError(transport)
-        if transport == "rccl" and model is None:
-            raise ValueError("the rccl transport gathers the model's device buffers: pass model=")
+    def __init__(self, rank: int, world: int, evaluate: Callable = None, model=None, transport: str = "dist",
+                 group=None):
+        _check_transport(transport, model, group)
         if evaluate is None and model is None:
             raise ValueError("pass evaluate= or model=")
-        self.rank, self.world, self.model, self.transport = rank, world, model, transport
+        self.rank, self.world, self.model, self.transport, self.group = rank, world, model, transport, group
         self.evaluate = evaluate if evaluate is not None else model.prior_loglike_batch
 
     def __call__(self, cubes: np.ndarray):
@@ -121,14 +136,10 @@ class ShardedPriorLogLike:
             theta_all = m.download_gathered_theta(self.world * pad)
             logl_all = m.download_gathered(self.world * pad)
         else:
-            import torch
-            import torch.distributed as dist
             th, ll = self.evaluate(rows)
-            mine = torch.from_numpy(np.concatenate([np.asarray(th, dtype=np.float64).reshape(pad, ndim),
-                                                    np.asarray(ll, dtype=np.float64).reshape(pad, 1)], axis=1).copy())
-            parts = [torch.empty_like(mine) for _ in range(self.world)]
-            dist.all_gather(parts, mine)
-            both = torch.cat(parts).numpy()
+            mine = np.concatenate([np.asarray(th, dtype=np.float64).reshape(pad, ndim),
+                                   np.asarray(ll, dtype=np.float64).reshape(pad, 1)], axis=1)
+            both = gather_rows(mine, self.world, self.transport, group=self.group).reshape(self.world * pad, ndim + 1)
             theta_all, logl_all = both[:, :ndim], both[:, ndim]
         keep = np.concatenate([np.arange(r * pad, r * pad + (h - l)) for r, (l, h) in enumerate(partition(n, self.world))])
         return np.ascontiguousarray(theta_all[keep]), np.ascontiguousarray(logl_all[keep])
@@ -138,15 +149,24 @@ class ShardedWalker:
     """The sampler's proposal walk (GpuRVModel.slice_walk) sharded over ranks: every rank runs the same sampler
     state (same seed), walks its contiguous share of the replacement walkers on its GPU, and one all-gather
     returns every walker's end point (cube, theta, log-L) and the call count to every rank.  Drop-in for the
-    `walker=` argument of nested.run_nested_slice.  Each rank derives its own seed from the common one (walker
-    indices restart at 0 in every shard), so a run is reproducible for a given seed AND rank count."""
+    `walker=` argument of nested.run_nested_slice.
 
-    def __init__(self, rank: int, world: int, walk: Callable):
+    Every rank passes the COMMON seed and the index of its first row as `walker_base`: the walk's random numbers are
+    counter-based on (seed, walker_base + row, move, draw), so each walker draws exactly what it would in an
+    unsharded walk — a run is reproducible for a given seed whatever the rank count, and no two shards share a
+    random stream (deriving per-rank seeds by adding multiples of the counter increment made rank b replay rank
+    a's stream a few draws later).
+
+    walk(cube, theta, logl, lstar, chol, wrapped, nsteps, max_rounds, seed, walker_base=...) is
+    GpuRVModel.slice_walk in the product.  Transports as in ShardedLogLike ("rccl": model=, through
+    rvll_allgather_host)."""
+
+    def __init__(self, rank: int, world: int, walk: Callable, transport: str = "dist", model=None, group=None):
+        _check_transport(transport, model, group)
         self.rank, self.world, self.walk = rank, world, walk
+        self.transport, self.model, self.group = transport, model, group
 
     def __call__(self, cube, theta, logl, lstar, chol, wrapped, nsteps, max_rounds, seed):
-        import torch
-        import torch.distributed as dist
         cube = np.ascontiguousarray(cube, dtype=np.float64)
         theta = np.ascontiguousarray(theta, dtype=np.float64)
         logl = np.ascontiguousarray(logl, dtype=np.float64)
@@ -155,17 +175,16 @@ class ShardedWalker:
         pad = padded_count(n, self.world)
         mine = np.zeros((pad, 2 * ndim + 2))
         if hi > lo:
-            # a different seed per rank keeps the shards' random streams apart (walker indices restart at 0)
             c, t, l, used = self.walk(cube[lo:hi], theta[lo:hi], logl[lo:hi], lstar, chol, wrapped, nsteps,
-                                      max_rounds, (int(seed) + 0x9E3779B97F4A7C15 * (self.rank + 1)) % (2 ** 63))
+                                      max_rounds, int(seed), walker_base=lo)
             mine[: hi - lo, :ndim], mine[: hi - lo, ndim:2 * ndim], mine[: hi - lo, 2 * ndim] = c, t, l
             mine[0, 2 * ndim + 1] = used
-        parts = [torch.empty((pad, 2 * ndim + 2), dtype=torch.float64) for _ in range(self.world)]
-        dist.all_gather(parts, torch.from_numpy(mine))
-        both = torch.stack(parts).numpy()
+        if pad == 0:
+            return cube, theta, logl, 0
+        both = gather_rows(mine, self.world, self.transport, model=self.model, group=self.group)
         keep = [both[r, : h - l] for r, (l, h) in enumerate(partition(n, self.world))]
         out = np.concatenate(keep) if keep else np.empty((0, 2 * ndim + 2))
-        used_total = int(round(float(both[:, 0, 2 * ndim + 1].sum()))) if pad else 0
+        used_total = int(round(float(both[:, 0, 2 * ndim + 1].sum())))
         return (np.ascontiguousarray(out[:, :ndim]), np.ascontiguousarray(out[:, ndim:2 * ndim]),
                 np.ascontiguousarray(out[:, 2 * ndim]), used_total)
 
@@ -211,14 +230,15 @@ class MultiDeviceLogLike:
 
     def slice_walk(self, cube, theta, logl, lstar, chol, wrapped=None, nsteps=10, max_rounds=200, seed=0):
         """The proposal walk (GpuRVModel.slice_walk) with the walkers sharded over the devices; drop-in for the
-        `walker=` argument of nested.run_nested_slice.  Each device gets its own seed derived from `seed`."""
+        `walker=` argument of nested.run_nested_slice.  Every device gets the same seed and its first row as
+        walker_base, so the result does not depend on the number of devices (see ShardedWalker)."""
         cube = np.ascontiguousarray(cube, dtype=np.float64)
         theta = np.ascontiguousarray(theta, dtype=np.float64)
         logl = np.ascontiguousarray(logl, dtype=np.float64)
         bounds = partition(cube.shape[0], len(self.models))
         futures = [self._pool.submit(m.slice_walk, cube[lo:hi], theta[lo:hi], logl[lo:hi], lstar, chol, wrapped, nsteps,
-                                     max_rounds, (int(seed) + 0x9E3779B97F4A7C15 * (i + 1)) % (2 ** 63)) if hi > lo else None
-                   for i, (m, (lo, hi)) in enumerate(zip(self.models, bounds))]
+                                     max_rounds, int(seed), lo) if hi > lo else None
+                   for m, (lo, hi) in zip(self.models, bounds)]
         res = [f.result() for f in futures if f is not None]
         if not res:
             return cube, theta, logl, 0

@@ -225,10 +225,12 @@ int rvll_prior_loglike_batch(rvll_handle* h, const double* cube, int64_t B,
  * circular parameter, half a turn), candidate = uniform point of the chord -> prior transform -> log-L, accepted
  * if logL > lstar, else the chord shrinks towards the current point (at most max_rounds candidates per move).
  * In/out buffers return the end points; *ncalls = likelihood evaluations spent.  Deterministic for a given
- * seed.  Needs rvll_set_priors.                                                                              */
+ * seed: the random numbers are counter-based on (seed, walker_base + row, move, draw), so a rank that walks rows
+ * [lo, hi) of a larger set with walker_base = lo gets exactly what the unsharded walk gives those rows — a run does
+ * not depend on how many GPUs share it.  Needs rvll_set_priors.                                              */
 int rvll_slice_walk(rvll_handle* h, double* cube, double* theta, double* logl, int64_t K, double lstar,
                     const double* chol, const int32_t* wrapped /*[ndim] or NULL*/, int32_t nsteps,
-                    int32_t max_rounds, uint64_t seed, int64_t* ncalls);
+                    int32_t max_rounds, uint64_t seed, int64_t walker_base, int64_t* ncalls);
 
 /* ---- scalar-callback latency ------------------------------------------------------------------------- */
 /* PolyChord's loglike(theta) is irreducibly scalar (evidence/polychord/__init__.py:166-171): one theta per call.
@@ -290,6 +292,20 @@ int rvll_set_kernel_form(rvll_handle* h, int32_t form);
 int rvll_comm_unique_id(unsigned char id[RVLL_COMM_ID_BYTES]);
 int rvll_comm_init(rvll_handle* h, const unsigned char id[RVLL_COMM_ID_BYTES],
                    int32_t nranks, int32_t rank);
+/* rvll_comm_init gives ONE pipeline lane (the gather runs in-stream behind its kernel).  Further lanes — a stream,
+ * a communicator (ncclCommSplit of the first) and buffers each, so that the gather of step k overlaps the kernel of
+ * step k+1 — are added collectively: every rank calls rvll_comm_add_lanes, the ranks agree on the minimum of the
+ * counts it returned (out of band), and every rank calls rvll_comm_set_lanes with that number.  Ranks cycling
+ * through different numbers of communicators would hang their collectives.                                    */
+int rvll_comm_add_lanes(rvll_handle* h, int32_t want, int32_t* have);
+int rvll_comm_set_lanes(rvll_handle* h, int32_t nlanes);
+/* All-gather of a small host buffer over the same communicator (n_local doubles per rank up, nranks * n_local
+ * back, rank-major): what a sampler that shards host-side state over the ranks exchanges per iteration.        */
+int rvll_allgather_host(rvll_handle* h, const double* mine, int64_t n_local, double* all /*[nranks * n_local]*/);
+/* Which libraries this process actually runs on, as a JSON object: HIP runtime version and path of libamdhip64,
+ * path and version of the librccl that was loaded (RVLL_RCCL_PATH, else the one next to that libamdhip64, else
+ * /opt/rocm/lib, else by soname), path of librvll itself.                                                      */
+int rvll_runtime_info(char* buf, int32_t buflen);
 /* One multi-GPU step is rvll_dev_loglike(B_local) followed by rvll_allgather_logl(B_local): every rank's
  * per-shard log-L (the buffer the kernel just wrote) is all-gathered on the device, rank-major, so that every
  * rank — rank 0 owns the sampler's replacement step — holds all nranks*B_local values.  Asynchronous.  Steps

@@ -22,3 +22,4 @@ python3 scripts/pmc_summary.py "$OUT/pmc*/*/*_counter_collection.csv" > $OUT/pmc
 cat $OUT/kernel_stats.csv
 grep -h "^{" $OUT/stats.log | tail -1 > $OUT/bench_under_profiler.json || true
 cat $OUT/pmc_summary.txt
+python3 scripts/pmc_traffic_record.py $OUT > $OUT/pmc_traffic.json || true

@@ -169,3 +169,23 @@ def test_slim_walk_with_fat_finish_is_the_fat_walk(gpu_required, monkeypatch):
         assert np.array_equal(g[0], ref[0]) and np.array_equal(g[1], ref[1]) and np.array_equal(g[2], ref[2]), umax
     assert got[30.0][3] == ref[3]                 # nothing deferred: the same number of likelihood calls
     assert got[0.0][3] >= ref[3]                  # everything deferred at its first candidate, then redone
+
+
+def test_sharded_walk_draws_what_the_unsharded_walk_draws(gpu_required):
+    """walker_base: rows [lo, hi) walked on their own with walker_base = lo end where the full walk puts them —
+    the counters of the random numbers are (seed, walker_base + row, move, draw) — so a multi-GPU run
+    (sharded.ShardedWalker) is reproducible for a seed whatever the number of ranks."""
+    from evidence_amd.sharded import partition
+    w = make_workload(3)
+    with GpuRVModel(w.fixedpardict, w.table, w.parnames, priordict=w.priordict()) as m:
+        cube, theta, logl, lstar, chol = _start(m, w, 900, seed=31)
+        wr = wrapped_params(m.parnames)
+        full = m.slice_walk(cube, theta, logl, lstar, chol, wr, nsteps=7, seed=6)
+        for world in (2, 3):
+            parts = [m.slice_walk(cube[lo:hi], theta[lo:hi], logl[lo:hi], lstar, chol, wr, nsteps=7, seed=6, walker_base=lo)
+                     for lo, hi in partition(len(cube), world)]
+            assert np.array_equal(np.concatenate([p[0] for p in parts]), full[0]), world
+            assert np.array_equal(np.concatenate([p[2] for p in parts]), full[2]), world
+            assert sum(p[3] for p in parts) == full[3]
+        other = m.slice_walk(cube[:100], theta[:100], logl[:100], lstar, chol, wr, nsteps=7, seed=6, walker_base=100)
+    assert not np.array_equal(other[0], full[0][:100])            # other rows, other draws

@@ -1,0 +1,93 @@
+"""CPU: the torch-free control plane of the one-process-per-GPU runs (evidence_amd/rendezvous.py) at world sizes 2
+and 3 — the exchange bench.py and the sharded samplers use beside RCCL: id broadcast, barrier, max / min over ranks,
+all-gather of small host buffers — and the socket transport of the sharded log-L."""
+import multiprocessing as mp
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+REPO = Path(__file__).resolve().parents[1]
+
+
+def _worker(rank, world, address, q):
+    sys.path.insert(0, str(REPO))
+    from evidence_amd.rendezvous import Rendezvous
+    from evidence_amd.sharded import ShardedLogLike, ShardedWalker, partition
+    with Rendezvous(rank, world, address=address, timeout=30) as rz:
+        uid = rz.broadcast(bytes(range(128)) if rank == 0 else None, src=0)
+        got = rz.allgather({"rank": rank, "x": np.full(3, float(rank))})
+        rz.barrier()
+        mx, mn, sm = rz.allreduce(1.5 * rank, "max"), rz.allreduce(rank + 7, "min"), rz.allreduce(rank, "sum")
+        theta = np.random.default_rng(1).random((41, 4))
+        calls = []
+        def evaluate(x):
+            calls.append(len(x))
+            return -(x ** 2).sum(axis=1)
+        ll = ShardedLogLike(rank, world, evaluate=evaluate, transport="rdzv", group=rz)(theta)
+        def walk(cube, theta, logl, lstar, chol, wrapped, nsteps, max_rounds, seed, walker_base=0):
+            return cube + walker_base, theta, logl - seed, len(cube)
+        wc, wt, wl, used = ShardedWalker(rank, world, walk, transport="rdzv", group=rz)(
+            np.zeros((10, 2)), np.ones((10, 2)), np.arange(10.0), 0.0, np.eye(2), None, 3, 9, 5)
+        lo, hi = partition(41, world)[rank]
+        q.put((rank, uid == bytes(range(128)), [g["rank"] for g in got], float(got[-1]["x"][0]), mx, mn, sm,
+               bool(np.array_equal(ll, -(theta ** 2).sum(axis=1))), calls == [hi - lo],
+               wc[:, 0].tolist(), float(wl[3]), used))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_rendezvous_collectives_and_socket_transport(world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    address = f"unix:rvll-test-{os.getpid()}-{world}"
+    procs = [ctx.Process(target=_worker, args=(r, world, address, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=60) for _ in range(world))
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    from evidence_amd.sharded import partition
+    base = np.concatenate([np.full(hi - lo, float(lo)) for lo, hi in partition(10, world)]).tolist()
+    for rank, uid_ok, ranks, lastx, mx, mn, sm, ll_ok, calls_ok, wc0, wl3, used in results:
+        assert uid_ok and ranks == list(range(world)) and lastx == float(world - 1)
+        assert mx == 1.5 * (world - 1) and mn == 7 and sm == sum(range(world))
+        assert ll_ok and calls_ok
+        assert wc0 == base and wl3 == 3.0 - 5 and used == 10      # every shard saw the common seed and its own base
+
+
+def test_rendezvous_over_tcp_and_single_rank():
+    from evidence_amd.rendezvous import Rendezvous, default_address
+    with Rendezvous(0, 1) as rz:                                   # world 1: no socket at all
+        assert rz.allgather(5) == [5] and rz.allreduce(2.0, "max") == 2.0 and rz.broadcast("a") == "a"
+    assert default_address({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29512", "TORCHELASTIC_RUN_ID": "r7"}) == \
+        "unix:rvll-rdzv-127.0.0.1-29512-r7"
+    assert default_address({"RVLL_RDZV": "tcp://127.0.0.1:1234"}) == "tcp://127.0.0.1:1234"
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from evidence_amd.rendezvous import Rendezvous\n"
+            "r = Rendezvous(int(sys.argv[1]), 2, address=sys.argv[2], timeout=30)\n"
+            "print(r.allreduce(int(sys.argv[1]) + 1, 'sum')); r.close()\n") % str(REPO)
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), f"tcp://127.0.0.1:{port}"], stdout=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=60)[0].strip() for p in procs]
+    assert outs == ["3", "3"] and all(p.returncode == 0 for p in procs)
+
+
+def test_the_control_plane_and_the_bench_launch_path_do_not_import_torch():
+    """A process that imports torch first binds torch's bundled HIP runtime and RCCL: neither the
+    package, nor the rendezvous, nor bench.py may pull it in."""
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import evidence_amd, evidence_amd.rendezvous, evidence_amd.sharded, evidence_amd.nested, evidence_amd.callbacks\n"
+            "import importlib.util\n"
+            "spec = importlib.util.spec_from_file_location('b', %r); b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
+            "print('torch' in sys.modules)\n") % (str(REPO), str(REPO / "bench.py"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip() == "False"

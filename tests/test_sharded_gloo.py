@@ -110,10 +110,14 @@ def test_sharded_prior_loglike_returns_theta_and_logl_everywhere(world, n):
         assert calls == [padded_count(n, world)]                 # its own shard, padded to the common count
 
 
-def _fake_walk(cube, theta, logl, lstar, chol, wrapped, nsteps, max_rounds, seed):
-    """A deterministic stand-in for GpuRVModel.slice_walk (the GPU walk is tested in tests/test_gpu_walk.py)."""
-    c = (cube * 0.5 + 0.25) % 1.0
-    return c, 10.0 * c - 3.0, logl + 1.0, 3 * len(cube)
+def _fake_walk(cube, theta, logl, lstar, chol, wrapped, nsteps, max_rounds, seed, walker_base=0):
+    """A deterministic stand-in for GpuRVModel.slice_walk (the GPU walk is tested in tests/test_gpu_walk.py): like
+    the kernel, its "random" displacement is a counter-based function of (seed, walker_base + row)."""
+    ids = (np.arange(len(cube), dtype=np.uint64) + np.uint64(walker_base) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
+    z = (ids + np.uint64(seed)) ^ ((ids + np.uint64(seed)) >> np.uint64(31))
+    u = (z >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
+    c = (cube * 0.5 + u[:, None]) % 1.0
+    return c, 10.0 * c - 3.0, logl + u, 3 * len(cube)
 
 
 def _walk_worker(rank, world, port, n, q):
@@ -125,9 +129,9 @@ def _walk_worker(rank, world, port, n, q):
         rng = np.random.default_rng(3)
         cube, logl = rng.random((n, 4)), rng.normal(size=n)
         calls = []
-        def walk(*a):
-            calls.append(len(a[0]))
-            return _fake_walk(*a)
+        def walk(*a, **kw):
+            calls.append((len(a[0]), kw.get("walker_base")))
+            return _fake_walk(*a, **kw)
         out = ShardedWalker(rank, world, walk)(cube, 10.0 * cube - 3.0, logl, -1.0, np.eye(4), None, 5, 200, 17)
         q.put((rank, out, calls))
     finally:
@@ -149,8 +153,26 @@ def test_sharded_walker_gathers_every_walkers_end_point(world, n):
         assert p.exitcode == 0
     rng = np.random.default_rng(3)
     cube, logl = rng.random((n, 4)), rng.normal(size=n)
-    c, t, l, used = _fake_walk(cube, None, logl, 0, 0, 0, 0, 0, 0)
+    c, t, l, used = _fake_walk(cube, None, logl, 0, 0, 0, 0, 0, 17)            # the UNSHARDED walk, same seed
     for rank, (gc, gt, gl, gused), calls in results:
+        # every rank holds every walker's end point, and it is what the unsharded walk gives: the result depends on
+        # the seed only, not on the rank count (each shard passes the common seed and its first row as walker_base)
         assert np.array_equal(gc, c) and np.array_equal(gt, t) and np.array_equal(gl, l) and gused == 3 * n
         lo, hi = partition(n, world)[rank]
-        assert calls == ([hi - lo] if hi > lo else [])
+        assert calls == ([(hi - lo, lo)] if hi > lo else [])
+
+
+def test_shard_random_streams_do_not_overlap():
+    """per-shard seeds of the form seed + G*(rank+1), with G the counter increment of the generator,
+    made rank b replay rank a's stream a few draws later.  With a common seed and walker_base = first row the
+    (walker, move, draw) counters of different shards are disjoint by construction."""
+    n, world = 1000, 4
+    seen = set()
+    for lo, hi in partition(n, world):
+        ids = set(range(lo, hi))                      # walker_base + row for the rows of this shard
+        assert not (ids & seen)
+        seen |= ids
+    assert seen == set(range(n))
+    a = _fake_walk(np.zeros((5, 2)), None, np.zeros(5), 0, 0, 0, 0, 0, 9, walker_base=0)[0]
+    b = _fake_walk(np.zeros((5, 2)), None, np.zeros(5), 0, 0, 0, 0, 0, 9, walker_base=5)[0]
+    assert not np.intersect1d(a[:, 0], b[:, 0]).size  # different rows, different draws
