@@ -273,6 +273,7 @@ void debug_eval_kernel(int op, const double* x, const double* y, long long n, do
         case 11: r = __builtin_amdgcn_rcp(a); break;
         case 12: r = wave_sum(a); break;                 // lane 0 of every wave: the shuffle tree
         case 13: r = wave_sum_lane0(a); break;           //                        the same tree without the LDS crossbar
+        case 14: r = ndtri_cephes(a); break;
         default: r = NAN; break;
         }
         out[i] = r;

@@ -93,6 +93,70 @@ RVLL_HDF double ndtri_f64(double p)
     return q < 0. ? -val : val;
 }
 
+// ---- inverse normal CDF as scipy computes it: the algorithm of Cephes ndtri (S. L. Moshier, Cephes Math Library
+// 2.1; the routine behind scipy.special.ndtri and hence scipy.stats.norm.ppf / lognorm.ppf / alpha.ppf), restated
+// operation by operation: central region y + y (y^2 P0(y^2)/Q0(y^2)) scaled by sqrt(2 pi); tails x0 - x1 with
+// x = sqrt(-2 ln y), x0 = x - ln(x)/x, x1 = (1/x) P(1/x)/Q(1/x) on two sub-ranges.  Plain Horner steps with a
+// rounding after every multiply and add (scipy's build has no FMA) — compiled with -ffp-contract=off here.
+// Why a second routine next to AS241: the reference's Alpha quantile is 1/(a - ndtri(q Phi(a)))
+// (evidence/priors.py:375-376), which cancels as q -> 1, so a 1e-16 difference between two inverse-normal routines
+// becomes 1e-10 at q = 1 - 1e-6 and 1e-7 at 1 - 1e-9: to follow the reference there, the same routine has to be
+// evaluated.  (Coefficients: published tables of the Cephes routine.)
+RVLL_HDF double ndtri_cephes(double y0)
+{
+    constexpr double P0[5] = {-5.99633501014107895267E1, 9.80010754185999661536E1, -5.66762857469070293439E1,
+                              1.39312609387279679503E1, -1.23916583867381258016E0};
+    constexpr double Q0[8] = {1.95448858338141759834E0, 4.67627912898881538453E0, 8.63602421390890590575E1,
+                              -2.25462687854119370527E2, 2.00260212380060660359E2, -8.20372256168333339912E1,
+                              1.59056225126211695515E1, -1.18331621121330003142E0};
+    constexpr double P1[9] = {4.05544892305962419923E0, 3.15251094599893866154E1, 5.71628192246421288162E1,
+                              4.40805073893200834700E1, 1.46849561928858024014E1, 2.18663306850790267539E0,
+                              -1.40256079171354495875E-1, -3.50424626827848203418E-2, -8.57456785154685413611E-4};
+    constexpr double Q1[8] = {1.57799883256466749731E1, 4.53907635128879210584E1, 4.13172038254672030440E1,
+                              1.50425385692907503408E1, 2.50464946208309415979E0, -1.42182922854787788574E-1,
+                              -3.80806407691578277194E-2, -9.33259480895457427372E-4};
+    constexpr double P2[9] = {3.23774891776946035970E0, 6.91522889068984211695E0, 3.93881025292474443415E0,
+                              1.33303460815807542389E0, 2.01485389549179081538E-1, 1.23716634817820021358E-2,
+                              3.01581553508235416007E-4, 2.65806974686737550832E-6, 6.23974539184983293730E-9};
+    constexpr double Q2[8] = {6.02427039364742014255E0, 3.67983563856160859403E0, 1.37702099489081330271E0,
+                              2.16236993594496635890E-1, 1.34204006088543189037E-2, 3.28014464682127739104E-4,
+                              2.89247864745380683936E-6, 6.79019408009981274425E-9};
+    constexpr double s2pi = 2.50662827463100050242E0, expm2 = 0.13533528323661269189;
+    if (!(y0 > 0.)) return y0 == 0. ? -INFINITY : NAN;
+    if (!(y0 < 1.)) return y0 == 1. ? INFINITY : NAN;
+    bool negate = true;
+    double y = y0;
+    if (y > 1.0 - expm2) { y = 1.0 - y; negate = false; }
+    if (y > expm2) {
+        y = y - 0.5;
+        const double y2 = y * y;
+        double num = P0[0];
+        for (int i = 1; i < 5; ++i) num = num * y2 + P0[i];
+        double den = y2 + Q0[0];
+        for (int i = 1; i < 8; ++i) den = den * y2 + Q0[i];
+        double x = y + y * (y2 * num / den);
+        return x * s2pi;
+    }
+    double x = sqrt(-2.0 * log(y));
+    const double x0 = x - log(x) / x;
+    const double z = 1.0 / x;
+    double num, den;
+    if (x < 8.0) {
+        num = P1[0];
+        for (int i = 1; i < 9; ++i) num = num * z + P1[i];
+        den = z + Q1[0];
+        for (int i = 1; i < 8; ++i) den = den * z + Q1[i];
+    } else {
+        num = P2[0];
+        for (int i = 1; i < 9; ++i) num = num * z + P2[i];
+        den = z + Q2[0];
+        for (int i = 1; i < 8; ++i) den = den * z + Q2[i];
+    }
+    const double x1 = z * num / den;
+    x = x0 - x1;
+    return negate ? -x : x;
+}
+
 // ---- regularised incomplete beta ---------------------------------------------------------
 // Continued fraction of I_x(a,b), evaluated by the forward recurrence of its convergents
 // A_n/B_n, renormalised by B once per double step: one reciprocal per two terms instead of the
@@ -476,7 +540,7 @@ RVLL_HDF double alpha_ppf(double q, double a, double phi_a)
     if (q == 0.) return 0.;
     if (q == 1.) return INFINITY;
     if (!(q > 0. && q < 1.)) return NAN;
-    return 1.0 / (a - ndtri_f64(q * phi_a));
+    return 1.0 / (a - ndtri_cephes(q * phi_a));   // the reference's own routine: the difference cancels (see above)
 }
 
 }  // namespace rvll

@@ -190,9 +190,9 @@ __device__ double prior_light(const rvll_prior* priors, int D, const double* cub
     case RVLL_PRIOR_UNIFORMFREQUENCY:    // priors.py:100-101
         return pr.args[0] / (1 - q * (pr.args[1] - pr.args[0]) / pr.args[1]);
     case RVLL_PRIOR_NORMAL:              // stats.norm.ppf: loc + scale*ndtri(q)
-        return (q >= 0. && q <= 1.) ? ndtri_f64(q) * pr.args[1] + pr.args[0] : NAN;
+        return (q >= 0. && q <= 1.) ? ndtri_cephes(q) * pr.args[1] + pr.args[0] : NAN;
     case RVLL_PRIOR_LOGNORMAL:           // stats.lognorm.ppf: loc + scale*exp(s*ndtri(q))
-        return (q >= 0. && q <= 1.) ? exp(pr.args[0] * ndtri_f64(q)) * pr.args[2] + pr.args[1] : NAN;
+        return (q >= 0. && q <= 1.) ? exp(pr.args[0] * ndtri_cephes(q)) * pr.args[2] + pr.args[1] : NAN;
     case RVLL_PRIOR_TRUNCRAYLEIGH: {     // priors.py:249-252
         const double sg = pr.args[0], xm = pr.args[1];
         const double A = 1 - exp(-(xm * xm) / (2 * (sg * sg)));

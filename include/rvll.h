@@ -357,7 +357,8 @@ int rvll_fip_accumulate(int32_t device, const double* nua, const double* nub, in
 /* Evaluate one device math routine elementwise (tests only; no reference counterpart):
  * op 0 sin, 1 cos (rvll sincos), 2 div_exact(x,y), 3 x/y (IEEE), 4 div_fast(x,y),
  * 5 log_pos(x), 6 library log(x), 7 ndtri(x), 8/9 sin/cos after rotate_small by y, 10 div_1nr, 11 v_rcp_f64,
- * 12/13 the wave reduction tree by shuffles / by permlane-swap + DPP (lane 0 of every 64 values).           */
+ * 12/13 the wave reduction tree by shuffles / by permlane-swap + DPP (lane 0 of every 64 values), 14 the Cephes
+ * form of ndtri (scipy's routine; op 7 is AS241).                                                            */
 int rvll_debug_eval(rvll_handle* h, int32_t op, const double* x, const double* y,
                     int64_t n, double* out);
 

@@ -267,7 +267,10 @@ def gen_51peg():
 def gen_priors():
     rng = np.random.default_rng(9)
     q = np.concatenate([[0.0, 1e-300, 1e-12, 1e-6, 1e-3, 0.01, 0.1, 0.25, 0.37, 0.5, 0.63, 0.75, 0.9, 0.99, 0.999,
-                         1 - 1e-6, 1 - 1e-12, 1.0], rng.random(46)])
+                         1 - 1e-6, 1 - 1e-12, 1.0], rng.random(46),
+                        # round 2 (appended, so the indices above stay): the far tails, so that what the tests exclude
+                        # for the special-function kinds is a statement about fixtures, not a mask
+                        [1e-15, 1e-14, 1e-13, 1e-9, 1 - 1e-7, 1 - 1e-8, 1 - 1e-9, 1 - 1e-10, 1 - 1e-13, 1 - 1e-15]])
     sets = [
         ("Uniform", (4, 6)), ("Uniform", (-10, 10)), ("Uniform", (0.0, 2 * np.pi)),
         ("Jeffreys", (10, 100)), ("Jeffreys", (0.1, 100.0)),

@@ -6,6 +6,7 @@
 #define HM extern "C" __attribute__((visibility("default")))
 HM void hm_sincos(const double* x, long n, double* s, double* c) { for (long i = 0; i < n; ++i) rvll::sincos_f64(x[i], s[i], c[i]); }
 HM void hm_ndtri(const double* p, long n, double* out) { for (long i = 0; i < n; ++i) out[i] = rvll::ndtri_f64(p[i]); }
+HM void hm_ndtri_cephes(const double* p, long n, double* out) { for (long i = 0; i < n; ++i) out[i] = rvll::ndtri_cephes(p[i]); }
 HM void hm_beta_ppf(const double* q, long n, double a, double b, double lbeta, double* out) { for (long i = 0; i < n; ++i) out[i] = rvll::beta_ppf(q[i], a, b, lbeta); }
 HM void hm_gamma_ppf(const double* q, long n, double alpha, double beta, double lgam, double* out) { for (long i = 0; i < n; ++i) out[i] = rvll::gamma_ppf(q[i], alpha, beta, lgam); }
 HM void hm_alpha_ppf(const double* q, long n, double a, double phi_a, double* out) { for (long i = 0; i < n; ++i) out[i] = rvll::alpha_ppf(q[i], a, phi_a); }
