@@ -216,7 +216,7 @@ struct rvll_handle {
     rvll::ServerCtl* srv = nullptr;             // pinned, mapped, coherent
     rvll::ServerCtl* srv_dev = nullptr;         // its device address
     hipStream_t srv_stream = nullptr;
-    bool srv_enabled = false, srv_running = false;
+    bool srv_enabled = false, srv_running = false, srv_dead = false;
     unsigned long long srv_seq = 0;             // request numbers (low 32 bits travel)
     unsigned long long srv_last = 0;            // the last request word that was answered
     double*  d_srv_out = nullptr;               // device-local {logL, flags} the server's tile writes
@@ -265,7 +265,7 @@ int sync_other_lanes(rvll_handle* h)
 // collectives of its own handle (hipFree and friends synchronise the whole device).
 int server_stop(rvll_handle* h)
 {
-    if (!h->srv_running) return RVLL_OK;
+    if (!h->srv_running || h->srv_dead) return RVLL_OK;
     const unsigned long long request = ((unsigned long long)rvll::kServerQuit << 32) | (unsigned)++h->srv_seq;
     __atomic_store_n(&h->srv->request, request, __ATOMIC_RELEASE);
     hipError_t e = hipStreamSynchronize(h->srv_stream);
@@ -612,7 +612,8 @@ int rvll_create(const rvll_layout* layout, const double* time, const double* vra
         h->srv_dev = static_cast<rvll::ServerCtl*>(pd);
         CREATE_TRY(hipStreamCreateWithFlags(&h->srv_stream, hipStreamNonBlocking));
         CREATE_TRY(hipMalloc(&h->d_srv_out, 2 * sizeof(double)));
-        if (const char* e = getenv("RVLL_SCALAR_SERVER")) h->srv_enabled = atoi(e) != 0;
+        // the env switch obeys the same limit as rvll_scalar_server(): the control block holds kServerMaxDim parameters
+        if (const char* e = getenv("RVLL_SCALAR_SERVER")) h->srv_enabled = atoi(e) != 0 && layout->ndim <= rvll::kServerMaxDim;
     }
 
     const size_t nb = sizeof(double) * (size_t)n_epochs;
@@ -1117,6 +1118,10 @@ int server_start(rvll_handle* h)
 int scalar_call(rvll_handle* h, unsigned op, const double* theta, double* logL, int32_t* flags, double* theta_out)
 {
     rvll::ServerCtl* c = h->srv;
+    if (h->L.ndim > rvll::kServerMaxDim)
+        return fail(RVLL_E_UNSUPPORTED, "scalar server supports up to %d parameters", rvll::kServerMaxDim);
+    if (h->srv_dead)
+        return fail(RVLL_E_HIP, "the scalar server of this handle stopped answering earlier; destroy the handle");
     if (h->srv_running && __atomic_load_n(&c->state, __ATOMIC_ACQUIRE) == rvll::kServerExited) {
         HIP_TRY(hipStreamSynchronize(h->srv_stream));
         h->srv_running = false;
@@ -1146,8 +1151,15 @@ int scalar_call(rvll_handle* h, unsigned op, const double* theta, double* logL, 
             if (rc) return rc;
         }
         if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
-            (void)server_stop(h);
-            return fail(RVLL_E_HIP, "scalar server did not answer within 5 s");
+            // Post the quit word and mark the server dead WITHOUT waiting for the stream: if the persistent kernel is
+            // really stuck, a stream synchronisation would never return.  The kernel also leaves by itself after its
+            // idle timeout; the handle refuses further scalar calls and the caller should exit, not retry.
+            const unsigned long long quit = ((unsigned long long)rvll::kServerQuit << 32) | (unsigned)++h->srv_seq;
+            __atomic_store_n(&c->request, quit, __ATOMIC_RELEASE);
+            h->srv_last = quit;
+            h->srv_dead = true;
+            h->srv_enabled = false;
+            return fail(RVLL_E_HIP, "scalar server did not answer within 5 s (handle marked dead)");
         }
     }
     h->srv_last = request;
@@ -1215,16 +1227,20 @@ int rvll_loglike_batch(rvll_handle* h, const double* theta, int64_t B, double* l
         if (rc) return rc;
         HIP_TRY(hipStreamSynchronize(h->compute));
         const long long D = h->L.ndim;
+        // on an error in the middle of the loop, copies from the caller's buffers may still be in flight on either
+        // stream: wait for both before handing the buffers back
+        auto settle = [&]() { (void)hipStreamSynchronize(h->lanes[0]); (void)hipStreamSynchronize(h->lanes[1]); };
         for (int c = 0; c < nsplit; ++c) {
             const long long lo = B * c / nsplit, hi = B * (c + 1) / nsplit;
             hipStream_t st = h->lanes[c & 1];
-            HIP_TRY(hipMemcpyAsync(h->d_theta + lo * D, theta + lo * D, sizeof(double) * (size_t)((hi - lo) * D),
-                                   hipMemcpyHostToDevice, st));
+            { const hipError_t err_ = hipMemcpyAsync(h->d_theta + lo * D, theta + lo * D, sizeof(double) * (size_t)((hi - lo) * D),
+                                                     hipMemcpyHostToDevice, st);
+              if (err_ != hipSuccess) { settle(); HIP_TRY(err_); } }
             rvll::LoglikeArgs a;
             int cu = 0;
             rc = build_args(h, h->d_theta + lo * D, h->d_logL2[0] + lo, h->d_flags2[0] + lo, hi - lo, &a, &cu);
-            if (rc) return rc;
-            HIP_TRY(launch_form(a, cu, st));
+            if (rc) { settle(); return rc; }
+            { const hipError_t err_ = launch_form(a, cu, st); if (err_ != hipSuccess) { settle(); HIP_TRY(err_); } }
         }
         HIP_TRY(hipStreamSynchronize(h->lanes[1]));
         h->theta_async = false;
@@ -1316,31 +1332,35 @@ int rvll_prior_loglike_batch(rvll_handle* h, const double* cube, int64_t B,
         HIP_TRY(hipStreamSynchronize(h->compute));
         const long long D = h->L.ndim;
         auto bounds = [&](int c, long long* lo, long long* hi) { *lo = B * c / nsplit; *hi = B * (c + 1) / nsplit; };
+        // an error in the middle leaves copies to / from the caller's buffers in flight: settle both streams first
+        auto settle = [&](int code) { (void)hipStreamSynchronize(h->lanes[0]); (void)hipStreamSynchronize(h->lanes[1]); return code; };
+#define SPLIT_TRY(expr) do { const hipError_t err_ = (expr); if (err_ != hipSuccess) { settle(0); HIP_TRY(err_); } } while (0)
         auto fetch = [&](int c) -> int {
             long long lo, hi;
             bounds(c, &lo, &hi);
             hipStream_t st = h->lanes[c & 1];
-            if (theta_out) HIP_TRY(hipMemcpyAsync(theta_out + lo * D, h->d_theta + lo * D, sizeof(double) * (size_t)((hi - lo) * D), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(logL + lo, h->d_logL2[0] + lo, sizeof(double) * (size_t)(hi - lo), hipMemcpyDeviceToHost, st));
-            if (flags) HIP_TRY(hipMemcpyAsync(flags + lo, h->d_flags2[0] + lo, sizeof(int32_t) * (size_t)(hi - lo), hipMemcpyDeviceToHost, st));
+            if (theta_out) SPLIT_TRY(hipMemcpyAsync(theta_out + lo * D, h->d_theta + lo * D, sizeof(double) * (size_t)((hi - lo) * D), hipMemcpyDeviceToHost, st));
+            SPLIT_TRY(hipMemcpyAsync(logL + lo, h->d_logL2[0] + lo, sizeof(double) * (size_t)(hi - lo), hipMemcpyDeviceToHost, st));
+            if (flags) SPLIT_TRY(hipMemcpyAsync(flags + lo, h->d_flags2[0] + lo, sizeof(int32_t) * (size_t)(hi - lo), hipMemcpyDeviceToHost, st));
             return RVLL_OK;
         };
         for (int c = 0; c < nsplit; ++c) {
             long long lo, hi;
             bounds(c, &lo, &hi);
             hipStream_t st = h->lanes[c & 1];
-            HIP_TRY(hipMemcpyAsync(h->d_cube + lo * D, cube + lo * D, sizeof(double) * (size_t)((hi - lo) * D), hipMemcpyHostToDevice, st));
+            SPLIT_TRY(hipMemcpyAsync(h->d_cube + lo * D, cube + lo * D, sizeof(double) * (size_t)((hi - lo) * D), hipMemcpyHostToDevice, st));
             rvll::PriorArgs pa{h->d_cube + lo * D, h->d_theta + lo * D, hi - lo, h->L.ndim, h->d_priors, h->d_heavy, h->n_heavy};
-            HIP_TRY(rvll::launch_prior(pa, st));
+            SPLIT_TRY(rvll::launch_prior(pa, st));
             rvll::LoglikeArgs a;
             int cu = 0;
             rc = build_args(h, h->d_theta + lo * D, h->d_logL2[0] + lo, h->d_flags2[0] + lo, hi - lo, &a, &cu);
-            if (rc) return rc;
-            HIP_TRY(launch_form(a, cu, st));
-            if (c > 0) { rc = fetch(c - 1); if (rc) return rc; }
+            if (rc) return settle(rc);
+            SPLIT_TRY(launch_form(a, cu, st));
+            if (c > 0) { rc = fetch(c - 1); if (rc) return settle(rc); }
         }
         rc = fetch(nsplit - 1);
-        if (rc) return rc;
+        if (rc) return settle(rc);
+#undef SPLIT_TRY
         HIP_TRY(hipStreamSynchronize(h->compute));
         HIP_TRY(hipStreamSynchronize(h->lanes[1]));
         h->theta_async = false;

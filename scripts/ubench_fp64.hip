@@ -73,6 +73,13 @@ template <int V> __global__ __launch_bounds__(256, 4) void k(double* out, unsign
             a4 = (double)(float)a4 + c; a5 = (double)(float)a5 + c; a6 = (double)(float)a6 + c; a7 = (double)(float)a7 + c;
         } else if (V == 16) { // 4 x logf fast
             f0 = __logf(f0 + 2.f); f1 = __logf(f1 + 2.f); f2 = __logf(f2 + 2.f); f3 = __logf(f3 + 2.f);
+        } else if (V == 17) { // 4 x v_pk_fma_f32 (two fp32 fma each): does packing two Horner chains pay?
+            typedef float pk2 __attribute__((ext_vector_type(2)));
+            pk2 p0 = {f0, f1}, p1 = {f2, f3}, p2 = {f4, f5}, p3 = {f6, f7};
+            const pk2 mm = {0.999999f, 0.999998f}, c2 = {1e-7f, 2e-7f};
+            p0 = __builtin_elementwise_fma(p0, mm, c2); p1 = __builtin_elementwise_fma(p1, mm, c2);
+            p2 = __builtin_elementwise_fma(p2, mm, c2); p3 = __builtin_elementwise_fma(p3, mm, c2);
+            f0 = p0.x; f1 = p0.y; f2 = p1.x; f3 = p1.y; f4 = p2.x; f5 = p2.y; f6 = p3.x; f7 = p3.y;
         }
     }
     a0 += (double)(f0 + f1 + f2 + f3 + f4 + f5 + f6 + f7) + (double)(i0 + i1 + i2 + i3 + i4 + i5 + i6 + i7);
@@ -122,5 +129,6 @@ int main()
     run<14>("cmp+select f32 x8", 8, out, clk, blocks);
     run<15>("cvt f64->f32->f64 (+1 add) x8", 8, out, clk, blocks);
     run<16>("__logf (+1 add) x4", 4, out, clk, blocks);
+    run<17>("v_pk_fma_f32 x4 (8 fp32 fma)", 4, out, clk, blocks);
     return 0;
 }

@@ -16,17 +16,28 @@ def _run(w, theta, precision):
         return m.log_likelihood_batch(theta)
 
 
+# (max, median) of the relative log-L error against the fp64 path, per config and mode: at most 5x what was measured on
+# the MI355X for these very samples (max 1.2e-7 / 1.4e-7 / 9.2e-8 for cfg2 / 3 / 5, medians 2.0e-10 ..
+# 3.5e-8), so a regression by an order of magnitude fails
+BOUNDS = {
+    (2, "mixed"): (6e-7, 1.0e-9), (2, "fp32"): (6e-7, 1.8e-7),
+    (3, "mixed"): (7e-7, 1.6e-8), (3, "fp32"): (7.5e-7, 1.7e-7),
+    (5, "mixed"): (4.6e-7, 1.2e-8), (5, "fp32"): (4.6e-7, 5.5e-8),
+}
+
+
 @pytest.mark.parametrize("cfg,n", [(2, 4096), (3, 8192), (5, 1024)])
 def test_tolerance_sweep(gpu_required, cfg, n):
     w = make_workload(cfg)
     theta = w.sample_theta(n, seed=321 + cfg)
     ref = _run(w, theta, "fp64")
-    for precision, bound_max, bound_med in (("mixed", 2e-5, 2e-7), ("fp32", 5e-5, 1e-6)):
+    for precision in ("mixed", "fp32"):
+        bound_max, bound_med = BOUNDS[(cfg, precision)]
         got = _run(w, theta, precision)
         err = golden.rel_err(got, ref)
         print(f"cfg{cfg} {precision}: max {err.max():.2e} median {np.median(err):.2e} p99 {np.percentile(err, 99):.2e} "
               f"max abs {np.max(np.abs(got - ref)):.3e}")
-        assert err.max() <= bound_max and np.median(err) <= bound_med, (cfg, precision, float(err.max()))
+        assert err.max() <= bound_max and np.median(err) <= bound_med, (cfg, precision, float(err.max()), float(np.median(err)))
 
 
 def test_reduced_precision_keeps_sentinels_and_phase_range(gpu_required):
