@@ -312,6 +312,8 @@ def run_extras(out, model, w, theta, B, with_cpu):
             model.dev_sync()
             return reps * n / (time.perf_counter() - t1)
         out["prior_plus_loglike_evals_per_s"] = timed(B, lambda: (model.dev_prior(B), model.dev_loglike(B)), 50)
+        # the same in ONE launch: the slim prior stage in front of the CU-wide log-L tile (rvll_dev_prior_loglike)
+        out["prior_plus_loglike_one_launch_evals_per_s"] = timed(B, lambda: model.dev_prior_loglike(B), 50)
         # a sampler's proposal round: a small batch, where a launch is a large part of the step — the prior transform
         # in the log-L tile's staging step (one launch) against prior kernels + log-L kernel; a sync per step, as a
         # sampler that looks at every result would have

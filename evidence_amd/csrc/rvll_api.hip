@@ -151,7 +151,7 @@ void dev_free(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
 
 constexpr int kMaxLanes = 4;
 // rvll_loglike_batch: host batches from kSplitMinPoints on go up in overlapped chunks of about kSplitChunkPoints
-constexpr long long kSplitMinPoints = 16384, kSplitChunkPoints = 32768, kSplitMaxChunks = 8;
+constexpr long long kSplitMinPoints = 16384, kSplitChunkPoints = 16384, kSplitMaxChunks = 8;   // profiles/r02_split_probe.txt
 constexpr long long kFusedMaxPoints = 4096;   // rvll_prior_loglike_batch: one launch up to here, two beyond
 
 struct rvll_handle {
@@ -879,6 +879,11 @@ int rvll_dev_loglike(rvll_handle* h, int64_t B)
         HIP_TRY(hipStreamSynchronize(h->compute));
         h->theta_async = false;
     }
+    // launches that alternate pipeline lanes keep two kernels in flight: that decides the launch form and geometry
+    // (choose_cu_form, choose_points_per_block) and is re-derived per launch, so a handle that went back to one lane
+    // goes back to the single-stream choices
+    const bool alternating = lane != h->logl_last;
+    if (alternating != h->pipelined) { h->pipelined = alternating; h->geo.clear(); }
     rvll::LoglikeArgs a;
     int cu = 0;
     rc = build_args(h, h->d_theta, h->d_logL2[lane], h->d_flags2[lane], B, &a, &cu);
@@ -890,15 +895,18 @@ int rvll_dev_loglike(rvll_handle* h, int64_t B)
 
 int rvll_dev_prior_loglike(rvll_handle* h, int64_t B)
 {
+    // Back-to-back one-launch batches over the same buffers stay asynchronous: the deferral word is sticky (cleared
+    // only by resolve_fused), only the LATEST batch's results can still be looked at, and whoever looks at them goes
+    // through use_device -> resolve_fused first — so the pending mark is carried over instead of resolved here.
+    if (h) h->fused_pending = 0;
     int rc = use_device(h);
     if (rc) return rc;
     if (!h->have_priors) return fail(RVLL_E_NOPRIORS, "rvll_set_priors has not been called");
     if (B < 0 || B > h->cap) return fail(RVLL_E_INVALID, "B %lld outside reserved capacity %lld", (long long)B, h->cap);
     if (B == 0) return RVLL_OK;
-    // One launch (the prior transform in the log-L tile's staging step) pays for small batches, where a launch is a
-    // large part of the step, and needs every Beta / Gamma prior to have a verified table (the slim stage).  Otherwise:
-    // the prior kernels, then the log-L kernel in whichever form the batch size selects.
-    if (B > kFusedMaxPoints || !h->all_direct || h->form_override == 2) {
+    // One launch (the prior transform in the log-L tile's staging step) needs every Beta / Gamma prior to have a
+    // verified table (the slim stage); otherwise: the prior kernels, then the log-L kernel.
+    if (!h->all_direct) {
         rc = rvll_dev_prior(h, B);
         if (rc) return rc;
         if (h->logl_cur != 0) h->logl_cur = 0;     // results of this call live on lane 0, as the one-launch form's do
@@ -907,11 +915,13 @@ int rvll_dev_prior_loglike(rvll_handle* h, int64_t B)
     rc = sync_other_lanes(h);                  // theta is rewritten: no other lane may still be reading it
     if (rc) return rc;
     rvll::LoglikeArgs a;
-    rc = build_args(h, h->d_theta, h->d_logL2[0], h->d_flags2[0], B, &a);
+    int cu = 0;                                // small batches: 256-thread tiles; larger ones: the CU-wide form, as for plain log-L
+    h->pipelined = false;
+    rc = build_args(h, h->d_theta, h->d_logL2[0], h->d_flags2[0], B, &a, B > kFusedMaxPoints ? &cu : nullptr);
     if (rc) return rc;
     make_fused(h, h->d_cube, h->d_theta, &a);
-    *h->pin_defer = 0;                         // no slim launch is in flight here: use_device resolved the last one
-    HIP_TRY(rvll::launch_prior_loglike(a, h->compute));
+    if (cu > 0) HIP_TRY(rvll::launch_loglike_cu(a, cu, h->compute));
+    else        HIP_TRY(rvll::launch_prior_loglike(a, h->compute));
     h->theta_async = true;
     h->logl_last = 0;
     h->fused_pending = B;                      // whoever touches the results next looks at the defer word first
@@ -939,7 +949,32 @@ int rvll_dev_download(rvll_handle* h, int64_t B, double* theta, double* logL, in
             if (nf) memcpy(flags, p + nt + nl, nf);
             return RVLL_OK;
         }
-        if (theta) HIP_TRY(hipMemcpyAsync(theta, h->d_theta, nt, hipMemcpyDeviceToHost, h->compute));
+        if (theta) {
+            // A large device-to-host copy into PAGEABLE memory crawls (40 MB of theta: 20 ms, 2 GB/s, whatever the
+            // chunking of the call — profiles/r02_split_probe.txt), while the same bytes into pinned memory move at
+            // PCIe speed: go through the two 1 MiB pinned staging buffers, the copy of chunk i+1 under the memcpy of
+            // chunk i.
+            constexpr size_t kDirectMax = 8u << 20, kChunk = rvll_handle::kPinBytes;
+            if (nt <= kDirectMax) {
+                HIP_TRY(hipMemcpyAsync(theta, h->d_theta, nt, hipMemcpyDeviceToHost, h->compute));
+            } else {
+                HIP_TRY(hipStreamSynchronize(h->compute));
+                char* dst = reinterpret_cast<char*>(theta);
+                const char* src = reinterpret_cast<const char*>(h->d_theta);
+                void* stage[2] = {h->pin_in, h->pin_out};
+                const size_t nchunks = (nt + kChunk - 1) / kChunk;
+                HIP_TRY(hipMemcpyAsync(stage[0], src, std::min(kChunk, nt), hipMemcpyDeviceToHost, h->compute));
+                for (size_t c = 0; c < nchunks; ++c) {
+                    const size_t off = c * kChunk, len = std::min(kChunk, nt - off);
+                    HIP_TRY(hipStreamSynchronize(h->compute));                    // chunk c has landed
+                    if (c + 1 < nchunks)
+                        HIP_TRY(hipMemcpyAsync(stage[(c + 1) & 1], src + off + kChunk, std::min(kChunk, nt - off - kChunk),
+                                               hipMemcpyDeviceToHost, h->lanes[1]));
+                    memcpy(dst + off, stage[c & 1], len);
+                    if (c + 1 < nchunks) HIP_TRY(hipStreamSynchronize(h->lanes[1]));
+                }
+            }
+        }
         if (logL)  HIP_TRY(hipMemcpyAsync(logL, h->d_logL2[h->logl_last], nl, hipMemcpyDeviceToHost, h->compute));
         if (flags) HIP_TRY(hipMemcpyAsync(flags, h->d_flags2[h->logl_last], nf, hipMemcpyDeviceToHost, h->compute));
     }
@@ -984,7 +1019,6 @@ int rvll_dev_flip_lane(rvll_handle* h)
 {
     if (!h) return fail(RVLL_E_INVALID, "null handle");
     h->logl_cur = (h->logl_cur + 1) % (h->nccl_comm[0] ? h->nlanes : h->nlanes_dev);
-    if (!h->pipelined) { h->pipelined = true; h->geo.clear(); }
     return h->logl_cur;
 }
 
@@ -1658,7 +1692,6 @@ int rvll_comm_set_lanes(rvll_handle* h, int32_t nlanes)
     }
     h->nlanes = nlanes;
     h->logl_cur = 0;
-    if (nlanes == 1 && h->pipelined) { h->pipelined = false; h->geo.clear(); }
     return RVLL_OK;
 }
 
@@ -1687,10 +1720,7 @@ int rvll_allgather_logl(rvll_handle* h, int64_t B_local)
     RCCL_TRY(g_rccl.AllGather(h->d_logL2[lane], h->d_gather2[lane], (size_t)B_local, kNcclFloat64,
                               h->nccl_comm[lane], lane_stream(h, lane)));
     h->gather_last = lane;
-    if (h->nlanes > 1) {
-        h->logl_cur = (lane + 1) % h->nlanes; // the next step runs on the next lane
-        if (!h->pipelined) { h->pipelined = true; h->geo.clear(); }
-    }
+    if (h->nlanes > 1) h->logl_cur = (lane + 1) % h->nlanes;   // the next step runs on the next lane
     return RVLL_OK;
 }
 

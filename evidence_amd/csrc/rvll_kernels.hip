@@ -23,8 +23,9 @@ namespace rvll {
 
 namespace {
 
-// The CU-wide form: one 1024-thread workgroup per tile of a.PB points (loglike_tile, NT = 1024, DYN)
-template <int PREC, bool TRACE>
+// The CU-wide form: one 1024-thread workgroup per tile of a.PB points (loglike_tile, NT = 1024, DYN); FUSED as in
+// loglike_kernel
+template <int PREC, bool TRACE, int FUSED = kFusedNone>
 __global__ __launch_bounds__(kCuThreads) __attribute__((flatten))
 void loglike_cu_kernel(const LoglikeArgs a)
 {
@@ -32,7 +33,7 @@ void loglike_cu_kernel(const LoglikeArgs a)
     const long long p0 = (long long)blockIdx.x * a.PB;
     const int npts = (int)min((long long)a.PB, a.B - p0);
     if (npts <= 0) return;
-    loglike_tile<PREC, kFusedNone, TRACE, kCuThreads, true>(a, smem, p0, npts);
+    loglike_tile<PREC, FUSED, TRACE, kCuThreads, true>(a, smem, p0, npts);
 }
 
 // 4 workgroups of 256 per CU (4 waves/SIMD): caps the kernel at 128 VGPRs
@@ -336,6 +337,8 @@ hipError_t launch_loglike_cu(const LoglikeArgs& a, int grid, hipStream_t stream)
     if (grid < 1 || (long long)grid * a.PB < a.B || a.PB < 1 || a.PB > kCuMaxPoints || (long long)a.CH < (long long)a.PB * a.Ne || lds > kCuLdsBudget ||
         (a.trace && a.precision != RVLL_PREC_FP64))
         return hipErrorInvalidValue;
+    const bool fused = a.cube != nullptr;                   // the slim prior stage in front (launch_prior_loglike's arguments)
+    if (fused && (!a.theta_out || !a.priors || (a.n_heavy > 0 && !a.heavy_dims) || a.trace)) return hipErrorInvalidValue;
     static bool attr_set_dev[64] = {};                      // raise the dynamic-LDS limit of every instance once per device
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -346,11 +349,22 @@ hipError_t launch_loglike_cu(const LoglikeArgs& a, int grid, hipStream_t stream)
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(loglike_cu_kernel<RVLL_PREC_MIXED, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(loglike_cu_kernel<RVLL_PREC_FP32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(loglike_cu_kernel<RVLL_PREC_FP64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(loglike_cu_kernel<RVLL_PREC_FP64, false, kFusedSlim>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(loglike_cu_kernel<RVLL_PREC_MIXED, false, kFusedSlim>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(loglike_cu_kernel<RVLL_PREC_FP32, false, kFusedSlim>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const dim3 g((unsigned)grid), block(kCuThreads);
     if (a.trace) { hipLaunchKernelGGL((loglike_cu_kernel<RVLL_PREC_FP64, true>), g, block, lds, stream, a); return hipGetLastError(); }
+    if (fused) {
+        switch (a.precision) {
+        case RVLL_PREC_MIXED: hipLaunchKernelGGL((loglike_cu_kernel<RVLL_PREC_MIXED, false, kFusedSlim>), g, block, lds, stream, a); break;
+        case RVLL_PREC_FP32:  hipLaunchKernelGGL((loglike_cu_kernel<RVLL_PREC_FP32, false, kFusedSlim>), g, block, lds, stream, a); break;
+        default:              hipLaunchKernelGGL((loglike_cu_kernel<RVLL_PREC_FP64, false, kFusedSlim>), g, block, lds, stream, a); break;
+        }
+        return hipGetLastError();
+    }
     switch (a.precision) {
     case RVLL_PREC_MIXED: hipLaunchKernelGGL((loglike_cu_kernel<RVLL_PREC_MIXED, false>), g, block, lds, stream, a); break;
     case RVLL_PREC_FP32:  hipLaunchKernelGGL((loglike_cu_kernel<RVLL_PREC_FP32, false>), g, block, lds, stream, a); break;
