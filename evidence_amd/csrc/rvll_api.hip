@@ -413,6 +413,12 @@ int choose_cu_form(rvll_handle* h, long long B, rvll::LoglikeArgs* a)
     const long long rounds = (ppc + pbmax - 1) / pbmax;             // tiles per CU
     if (!forced && rounds > 4) return 0;
     const int pb = (int)((B + ncu * rounds - 1) / (ncu * rounds));
+    if (!forced && rounds > 1) {
+        // several tiles per CU: each one's ~5 us of prologue + reduction is exposed, so the tile has to be long —
+        // wave rounds per wave x (0.9 + 1.33 Np) us per round (fitted to the sweep) — for the form to pay
+        const double t_tile_us = (double)pb * h->Ne / rvll::kWave / (rvll::kCuThreads / rvll::kWave) * (0.9 + 1.33 * h->L.nplanets);
+        if (t_tile_us < 40.0) return 0;
+    }
     a->PB = pb;
     a->CH = (pb * h->Ne + 1) & ~1;
     return (int)((B + pb - 1) / pb);

@@ -169,13 +169,21 @@ RVLL_HD double log_pos(double v)
     const double f = m - 1.0;
     const double s = div_fast(f, 2.0 + f);
     const double z = s * s;
-    double R = __builtin_fma(z, 1.479819860511658591e-01, 1.531383769920937332e-01);
-    R = __builtin_fma(z, R, 1.818357216161805012e-01);
-    R = __builtin_fma(z, R, 2.222219843214978396e-01);
-    R = __builtin_fma(z, R, 2.857142874366239149e-01);
-    R = __builtin_fma(z, R, 3.999999999940941908e-01);
-    R = __builtin_fma(z, R, 6.666666666666735130e-01);
-    R = R * z;
+    // one block of v_fma_f64 with the coefficients as third VGPR operands: hipcc lowers each Horner step to a
+    // v_mov_b64 (coefficient copy) + v_fmac_f64 (same arithmetic, 6 more instructions per log)
+    constexpr double L7 = 1.479819860511658591e-01, L6 = 1.531383769920937332e-01, L5 = 1.818357216161805012e-01,
+                     L4 = 2.222219843214978396e-01, L3 = 2.857142874366239149e-01, L2 = 3.999999999940941908e-01,
+                     L1 = 6.666666666666735130e-01;
+    double R;
+    asm("v_fma_f64 %0, %1, %2, %3\n\t"
+        "v_fma_f64 %0, %1, %0, %4\n\t"
+        "v_fma_f64 %0, %1, %0, %5\n\t"
+        "v_fma_f64 %0, %1, %0, %6\n\t"
+        "v_fma_f64 %0, %1, %0, %7\n\t"
+        "v_fma_f64 %0, %1, %0, %8\n\t"
+        "v_mul_f64 %0, %0, %1"
+        : "=&v"(R)
+        : "v"(z), "v"(L7), "v"(L6), "v"(L5), "v"(L4), "v"(L3), "v"(L2), "v"(L1));
     const double hfsq = 0.5 * f * f;
     const double dk = (double)k;
     // k ln2_hi - ((hfsq - (s (hfsq + R) + k ln2_lo)) - f)

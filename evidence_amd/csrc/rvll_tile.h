@@ -252,7 +252,10 @@ struct ItemCtx {
 };
 
 // One (point, epoch) item: returns ln sqrt(var) + res^2 / (2 var).
-template <int PREC>
+// FAILCHECK: honour the itmax marks of earlier solves (nu = 0 from the first failing epoch of that planet on).  The
+// first pass over a tile runs without it: the marks can only come from that very pass, and every point that got one
+// is re-evaluated with FAILCHECK afterwards (3b of loglike_tile) — so the normal path carries no reads of the marks.
+template <int PREC, bool FAILCHECK>
 __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx& cx, int pl, int j)
 {
     const double t  = a.t[j];
@@ -265,7 +268,8 @@ __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx&
     const double var = s2 + oj.y;                             // rvmodel:189-192 (oj.y = jitter^2 or 0)
 
     if (a.Np > 0) {
-        const bool point_failed = cx.anyfail[pl] != 0;
+        bool point_failed = false;
+        if constexpr (FAILCHECK) point_failed = cx.anyfail[pl] != 0;
         double ksum = 0.;
         for (int ip = 0; ip < a.Np; ++ip) {
             const double* P = cx.pp + (pl * a.Np + ip) * kPlanetFields;
@@ -275,7 +279,7 @@ __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx&
             const double  C0  = P[6];                                       // K e cos w
             const double ec = p23.y;
             double rv;
-            if (point_failed && j >= cx.jfail[pl * a.Np + ip]) {
+            if (FAILCHECK && point_failed && j >= cx.jfail[pl * a.Np + ip]) {
                 rv = p45.x + C0;            // nu left at 0 (rvmodel:488, trueanomaly.c:32-33)
             } else if constexpr (PREC == RVLL_PREC_FP64) {
                 // mean anomaly, rvmodel:459 — two roundings in (t-epoch), then mul, then add
@@ -363,6 +367,17 @@ __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx&
 #ifndef RVLL_DECODE_INLINE
 #define RVLL_DECODE_INLINE __forceinline__
 #endif
+// (point, epoch) of lane `lane` in a wave round that starts at flattened item i0 (wave-uniform): the division by the
+// run-time epoch count happens once per wave round on the scalar unit instead of ~20 vector instructions per item
+__device__ __forceinline__ void item_of(int i0, int lane, int Ne, int& pl, int& j)
+{
+    const int u0 = __builtin_amdgcn_readfirstlane(i0);
+    const int pl0 = u0 / Ne;
+    pl = pl0;
+    j = u0 - pl0 * Ne + lane;
+    while (j >= Ne) { j -= Ne; ++pl; }            // at most once when Ne >= 64
+}
+
 // LDS views of one workgroup's tile (carve()).
 struct TileLds {
     double *theta_s, *pp, *ins, *dr, *lin, *acc, *lay, *contrib;
@@ -608,16 +623,17 @@ __device__ __forceinline__ __attribute__((flatten)) void loglike_tile(const Logl
                 if (r * kWave >= cend) break;
                 const int i = r * kWave + lane;
                 if (i < cend) {
-                    const int pl = i / a.Ne;
-                    contrib[i] = eval_item<PREC>(a, cx, pl, i - pl * a.Ne);
+                    int pl, j;
+                    item_of(r * kWave, lane, a.Ne, pl, j);
+                    contrib[i] = eval_item<PREC, false>(a, cx, pl, j);
                 }
             }
             if constexpr (TRACE) { if (tid == 0) tr[4] = __builtin_amdgcn_s_memrealtime(); }
         } else {
             for (int i = base + tid; i < cend; i += NT) {
-                const int pl = i / a.Ne;
-                const int j  = i - pl * a.Ne;
-                contrib[i - base] = eval_item<PREC>(a, cx, pl, j);
+                int pl, j;
+                item_of(i - lane, lane, a.Ne, pl, j);            // i - lane = base + 64 wave + k NT: the same for the whole wave
+                contrib[i - base] = eval_item<PREC, false>(a, cx, pl, j);
             }
             if constexpr (TRACE) { if (lane == 0) tr[2 + wave] = __builtin_amdgcn_s_memrealtime(); }
         }
@@ -629,7 +645,7 @@ __device__ __forceinline__ __attribute__((flatten)) void loglike_tile(const Logl
         if (L.nfail[0] != 0) {
             for (int i = base + tid; i < cend; i += NT) {
                 const int pl = i / a.Ne;
-                if (L.anyfail[pl]) contrib[i - base] = eval_item<PREC>(a, cx, pl, i - pl * a.Ne);
+                if (L.anyfail[pl]) contrib[i - base] = eval_item<PREC, true>(a, cx, pl, i - pl * a.Ne);
             }
             __syncthreads();
         }
