@@ -39,7 +39,9 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
     if (nw <= 0) return;
     double* wu   = smem + ((cv.total_doubles + 1) & ~1);   // [PB][D] current positions
     double* dir  = wu + PB * D;                            // [PB][D] normals, then unit directions
-    double* tmin = dir + PB * D;                           // [PB]
+    double* lo_s = dir + PB * D;                           // [PB][D] per-coordinate chord limits of a starting move
+    double* hi_s = lo_s + PB * D;
+    double* tmin = hi_s + PB * D;                          // [PB]
     double* tmax = tmin + PB;
     double* tcur = tmax + PB;
     double* wl   = tcur + PB;
@@ -97,26 +99,41 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
             if (state[pl] == 0) dir[pl * D + k] = mine[cnt & 3];
         }
         __syncthreads();
-        // ... normalise, chord (one thread per walker); then the candidate position along the chord
+        // ... normalise: 1 / |dir| per walker (parked in tmin until the chord is known) ...
+        for (int ai = tid; ai < nact; ai += kThreads) {
+            const int pl = act[ai];
+            if (state[pl] != 0) continue;
+            double n2 = 0.;
+            for (int k = 0; k < D; ++k) n2 += dir[pl * D + k] * dir[pl * D + k];
+            tmin[pl] = 1. / sqrt(n2);
+        }
+        __syncthreads();
+        // ... unit direction and the chord limits of every coordinate, one lane per (walker, coordinate): the two
+        // divisions per coordinate used to run serially in ONE lane per walker ...
+        for (int i = tid; i < nact * D; i += kThreads) {
+            const int pl = act[i / D], k = i % D;
+            if (state[pl] != 0) continue;
+            const double d = dir[pl * D + k] * tmin[pl], u = wu[pl * D + k];
+            dir[pl * D + k] = d;
+            double lo = -INFINITY, hi = INFINITY;
+            if (d != 0.) {
+                if (w.wrapped[k]) {
+                    const double half = 0.5 / fabs(d);
+                    lo = -half; hi = half;
+                } else {
+                    const double t0 = (0. - u) / d, t1 = (1. - u) / d;
+                    lo = fmin(t0, t1); hi = fmax(t0, t1);
+                }
+            }
+            lo_s[pl * D + k] = lo; hi_s[pl * D + k] = hi;
+        }
+        __syncthreads();
+        // ... the chord (same max / min sequence over the coordinates as before); then the candidate position along it
         for (int ai = tid; ai < nact; ai += kThreads) {
             const int pl = act[ai];
             if (state[pl] == 0) {
-                double n2 = 0.;
-                for (int k = 0; k < D; ++k) n2 += dir[pl * D + k] * dir[pl * D + k];
-                const double inv = 1. / sqrt(n2);
                 double lo = -INFINITY, hi = INFINITY;
-                for (int k = 0; k < D; ++k) {
-                    const double d = dir[pl * D + k] * inv, u = wu[pl * D + k];
-                    dir[pl * D + k] = d;
-                    if (d == 0.) continue;
-                    if (w.wrapped[k]) {
-                        const double half = 0.5 / fabs(d);
-                        lo = fmax(lo, -half); hi = fmin(hi, half);
-                    } else {
-                        const double t0 = (0. - u) / d, t1 = (1. - u) / d;
-                        lo = fmax(lo, fmin(t0, t1)); hi = fmin(hi, fmax(t0, t1));
-                    }
-                }
+                for (int k = 0; k < D; ++k) { lo = fmax(lo, lo_s[pl * D + k]); hi = fmin(hi, hi_s[pl * D + k]); }
                 tmin[pl] = lo; tmax[pl] = hi;
                 round_of[pl] = 0;
                 state[pl] = 1;
@@ -176,7 +193,7 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
 size_t walk_lds_bytes(const LoglikeArgs& a)
 {
     const size_t base = (loglike_lds_bytes(a) + 15) & ~(size_t)15;
-    return base + sizeof(double) * ((size_t)2 * a.PB * a.D + 4 * a.PB) + sizeof(int) * (4 * a.PB + 2) + 16;
+    return base + sizeof(double) * ((size_t)4 * a.PB * a.D + 4 * a.PB) + sizeof(int) * (4 * a.PB + 2) + 16;
 }
 
 hipError_t launch_slice_walk(const LoglikeArgs& a, const WalkArgs& w, bool fat, hipStream_t stream)

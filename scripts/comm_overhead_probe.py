@@ -12,6 +12,10 @@ theta = w.sample_theta(B, seed=1)
 with GpuRVModel(w.fixedpardict, w.table, w.parnames) as m:
     m.dev_upload_theta(theta)
     m.comm_init(GpuRVModel.comm_unique_id(), 1, 0)
+    lanes = int(os.environ.get("RVLL_LANES", "3"))
+    if lanes > 1:
+        m.comm_set_lanes(m.comm_add_lanes(lanes))
+    print(f"lanes requested {lanes}; runtime {GpuRVModel.runtime_info()}", flush=True)
     for gather in (False, True, False, True):
         for _ in range(300):
             m.dev_loglike(B)

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import golden
-from evidence_amd import GpuRVModel
+from evidence_amd import GpuRVModel, RvllError
 from evidence_amd.callbacks import make_polychord_callbacks, make_ultranest_callbacks, wrapped_params
 from evidence_amd.nested import run_nested
 from evidence_amd.sharded import ShardedLogLike
@@ -226,19 +226,61 @@ def test_pipeline_lanes_give_identical_results_and_order_theta_updates(gpu_requi
         assert np.array_equal(logl, m.log_likelihood_batch(theta))
 
 
-def test_single_lane_fallback_gathers_in_stream(gpu_required, monkeypatch):
-    """Without ncclCommSplit (forced here with RVLL_SINGLE_LANE) the step degrades to one lane: the gather runs
-    in-stream behind its kernel.  Same values."""
-    monkeypatch.setenv("RVLL_SINGLE_LANE", "1")
+def test_pipeline_lanes_are_added_collectively_and_every_lane_gathers(gpu_required):
+    """rvll_comm_init gives one lane (the gather runs in-stream behind its kernel); rvll_comm_add_lanes splits further
+    communicators and rvll_comm_set_lanes applies the count the ranks agreed on (here: one rank).  Steps then cycle
+    through the lanes — each with its own stream, communicator and buffers — and every lane's gather returns the
+    values of the kernel that ran on it; going back to one lane works too."""
     case = golden.config_case(3)
+    n = len(case.theta)
     with GpuRVModel(case.fixed, case.table, case.parnames) as m:
-        m.comm_init(GpuRVModel.comm_unique_id(), 1, 0)
         want = m.log_likelihood_batch(case.theta)
+        m.comm_init(GpuRVModel.comm_unique_id(), 1, 0)
         m.dev_upload_theta(case.theta)
-        for _ in range(4):
-            m.dev_loglike(len(case.theta))
-            m.allgather_logl(len(case.theta))
-        assert np.array_equal(m.download_gathered(len(case.theta)), want)
+        for _ in range(3):                                   # one lane
+            m.dev_loglike(n)
+            m.allgather_logl(n)
+        assert np.array_equal(m.download_gathered(n), want)
+        have = m.comm_add_lanes(3)
+        assert 1 <= have <= 3
+        m.comm_set_lanes(have)
+        for k in range(2 * have + 1):                        # every lane, more than once
+            m.dev_loglike(n)
+            m.allgather_logl(n)
+            assert np.array_equal(m.download_gathered(n), want), k
+        with pytest.raises(RvllError):
+            m.comm_set_lanes(have + 1 if have < 4 else 5)    # more lanes than communicators
+        m.comm_set_lanes(1)
+        m.dev_loglike(n)
+        m.allgather_logl(n)
+        assert np.array_equal(m.download_gathered(n), want)
+        info = GpuRVModel.runtime_info()
+        assert info["librccl"].endswith(("librccl.so.1", "librccl.so")) and info["rccl_version"] > 0
+        assert info["libamdhip64"].rsplit("/", 1)[0] == info["librccl"].rsplit("/", 1)[0]     # the pair from one ROCm
+        m.comm_destroy()
+
+
+def test_host_rows_over_rccl_and_the_sharded_walker(gpu_required):
+    """rvll_allgather_host (one rank): the sampler's sharded host state goes through the device and RCCL and comes
+    back; ShardedWalker on that transport returns what the plain walk returns."""
+    from evidence_amd.callbacks import wrapped_params
+    from evidence_amd.sharded import ShardedWalker
+    w = make_workload(3)
+    with GpuRVModel(w.fixedpardict, w.table, w.parnames, priordict=w.priordict()) as m:
+        m.comm_init(GpuRVModel.comm_unique_id(), 1, 0)
+        x = np.random.default_rng(0).normal(size=(37, 5))
+        assert np.array_equal(m.allgather_host(x, 1).reshape(x.shape), x)
+        cube = np.random.default_rng(1).random((500, m.ndim))
+        theta, logl = m.prior_loglike_batch(cube)
+        lstar = float(np.median(logl))
+        keep = logl > lstar
+        chol = np.eye(m.ndim) * 0.1
+        wr = wrapped_params(m.parnames)
+        plain = m.slice_walk(cube[keep], theta[keep], logl[keep], lstar, chol, wr, nsteps=5, seed=3)
+        sharded = ShardedWalker(0, 1, m.slice_walk, transport="rccl", model=m)(
+            cube[keep], theta[keep], logl[keep], lstar, chol, wr, 5, 200, 3)
+        for a, b in zip(plain, sharded):
+            assert np.array_equal(a, b)
         m.comm_destroy()
 
 
