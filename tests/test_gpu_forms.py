@@ -84,3 +84,36 @@ def test_every_golden_case_in_cu_form(gpu_required):
             got = m.log_likelihood_batch(case.theta)
         err = golden.rel_err(got, case.logL)
         assert err.max() <= 1e-10, (case.name, float(err.max()))
+
+
+@pytest.mark.parametrize("n_epochs,nplanets,ninst,drift,nlin,only_offset,npts", [
+    (1, 1, 1, False, 0, False, 300),          # a single epoch: 64 points per wave round
+    (3, 0, 2, True, 0, False, 513),           # no planet at all, drift only
+    (17, 2, 1, False, 1, False, 1000),        # several points per wave round
+    (63, 8, 5, True, 3, False, 257),          # many planets / instruments / linear terms, ragged batch
+    (64, 1, 1, False, 0, False, 129), (65, 1, 3, True, 2, False, 129),
+    (127, 3, 2, False, 0, False, 2049),
+    (200, 2, 2, False, 0, True, 1000),        # exactly one free parameter
+    (2500, 4, 3, True, 1, False, 700),        # big tiles: a few points fill the LDS budget
+    (15000, 1, 1, False, 0, False, 40),       # one point per tile, four 4096-slices per point
+])
+def test_unusual_model_shapes_in_both_forms(gpu_required, n_epochs, nplanets, ninst, drift, nlin, only_offset, npts):
+    """Random model shapes through the tile form, the CU-wide form (forced) and the oracle: the wave-round index
+    arithmetic (several points per round when there are fewer than 64 epochs), tile sizing against the LDS budget
+    and the per-point slices all have to agree."""
+    from oracle.oracle import OracleModel
+    from test_gpu_loglike import _synthetic_case
+    rng = np.random.default_rng(n_epochs * 37 + nplanets)
+    table, free, fixed, ranges, linpar = _synthetic_case(rng, n_epochs, nplanets, ninst, drift, nlin, only_offset)
+    theta = np.stack([rng.uniform(*ranges[nm], npts) for nm in free], axis=1)
+    with GpuRVModel(fixed, table, free, linpar_dict=linpar or None) as m:
+        got = _both(m, theta)
+        layout = m.layout
+        m.set_kernel_form("cu")
+        m.dev_upload_theta(theta)
+        tm = m.dev_time_loglike(npts, warmup=0, iters=1)
+    assert np.array_equal(got["tile"][0], got["cu"][0]) and np.array_equal(got["tile"][1], got["cu"][1])
+    assert tm["threads"] == 1024                      # every one of these shapes fits the CU-wide form
+    series = np.stack([linpar[k] for k in layout.linpar_names]) if layout.linpar_names else None
+    ref = OracleModel(layout, table, series).loglike(theta, nthreads=8)
+    assert golden.rel_err(got["cu"][0], ref).max() <= 1e-10
