@@ -28,14 +28,39 @@ RVLL_HD uint64_t as_u64(double d) { return __builtin_bit_cast(uint64_t, d); }
 // v_fma_f64: hipcc otherwise lowers each step to v_mov_b64 (coefficient copy) + v_fmac_f64,
 // which costs a third of the sin/cos time on an issue-bound fp64 pipe, and it pads
 // separate asm statements with s_nop.  Pure VALU: no memory operations, no hazards.
-RVLL_HD void sincos_kernel(double r, double& sr, double& cr)
+// The constants of sincos_f64 as VALUES: by default compile-time constants the compiler places as it likes (the batch
+// kernels: hoisted out of the Newton loop by loop-invariant code motion).  A translation unit built without machine LICM
+// (rvll_walk.hip) defines RVLL_LOCAL_CONSTS and gets them as opaque register values it creates once in front of the loop
+// (sincos_consts_pinned) — same numbers, same instructions, only where the registers are loaded differs.
+struct SincosConsts {
+    double S1, S2, S3, S4, S5, S6, C1, C2, C3, C4, C5, C6, TWO_OVER_PI, PIO2_HI, PIO2_LO, MAGIC;
+};
+RVLL_HD SincosConsts sincos_consts()
 {
-    constexpr double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
-                     S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
-                     S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
-    constexpr double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
-                     C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
-                     C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    return SincosConsts{-1.66666666666666324348e-01, 8.33333333332248946124e-03, -1.98412698298579493134e-04,
+                        2.75573137070700676789e-06, -2.50507602534068634195e-08, 1.58969099521155010221e-10,
+                        4.16666666666666019037e-02, -1.38888888888741095749e-03, 2.48015872894767294178e-05,
+                        -2.75573143513906633035e-07, 2.08757232129817482790e-09, -1.13596475577881948265e-11,
+                        6.36619772367581382433e-01, 1.57079632679489655800e+00, 6.12323399573676603587e-17,
+                        6755399441055744.0};
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ SincosConsts sincos_consts_pinned()
+{
+    SincosConsts k = sincos_consts();
+    asm volatile("" : "+s"(k.S1), "+s"(k.S2), "+s"(k.S3), "+s"(k.S4), "+s"(k.S5), "+v"(k.S6));
+    asm volatile("" : "+s"(k.C1), "+s"(k.C2), "+s"(k.C3), "+s"(k.C4), "+s"(k.C5), "+v"(k.C6));
+    asm volatile("" : "+s"(k.TWO_OVER_PI), "+s"(k.PIO2_HI), "+s"(k.PIO2_LO), "+v"(k.MAGIC));
+    return k;
+}
+#else
+RVLL_HD SincosConsts sincos_consts_pinned() { return sincos_consts(); }
+#endif
+
+RVLL_HD void sincos_kernel(double r, double& sr, double& cr, const SincosConsts& k)
+{
+    const double S1 = k.S1, S2 = k.S2, S3 = k.S3, S4 = k.S4, S5 = k.S5, S6 = k.S6;
+    const double C1 = k.C1, C2 = k.C2, C3 = k.C3, C4 = k.C4, C5 = k.C5, C6 = k.C6;
 #if defined(__HIP_DEVICE_COMPILE__)
     double z, t;
     asm("v_mul_f64 %2, %4, %4\n\t"
@@ -76,12 +101,12 @@ RVLL_HD void sincos_kernel(double r, double& sr, double& cr)
 }
 
 // sin and cos of x, one shared range reduction.
-RVLL_HD void sincos_f64(double x, double& s_out, double& c_out)
+RVLL_HD void sincos_f64(double x, double& s_out, double& c_out, const SincosConsts& k)
 {
-    constexpr double TWO_OVER_PI = 6.36619772367581382433e-01;
-    constexpr double PIO2_HI     = 1.57079632679489655800e+00;  // 0x3FF921FB54442D18
-    constexpr double PIO2_LO     = 6.12323399573676603587e-17;  // pi/2 - PIO2_HI
-    constexpr double MAGIC       = 6755399441055744.0;          // 1.5 * 2^52
+    const double TWO_OVER_PI = k.TWO_OVER_PI;
+    const double PIO2_HI     = k.PIO2_HI;                       // 0x3FF921FB54442D18
+    const double PIO2_LO     = k.PIO2_LO;                       // pi/2 - PIO2_HI
+    const double MAGIC       = k.MAGIC;                         // 1.5 * 2^52
 
     // k = nearest integer to x*2/pi, via the round-to-nearest-even of the add;
     // its low bits sit in the low mantissa word of t.
@@ -93,7 +118,7 @@ RVLL_HD void sincos_f64(double x, double& s_out, double& c_out)
     const double r1 = __builtin_fma(-fk, PIO2_HI, x);
     const double r  = __builtin_fma(-fk, PIO2_LO, r1);
     double sr, cr;
-    sincos_kernel(r, sr, cr);
+    sincos_kernel(r, sr, cr, k);
 
     // quadrant: q&1 swaps, bit 1 of q flips sin, bit 1 of (q+1) flips cos.  Done with bit selects
     // (v_bfi_b32 / v_xor_b32, ~2 cycles each) rather than compare + v_cndmask (~4 cycles each, measured).
@@ -122,6 +147,8 @@ RVLL_HD void sincos_f64(double x, double& s_out, double& c_out)
     s_out = as_double(((uint64_t)rs_hi << 32) | rs_lo);
     c_out = as_double(((uint64_t)rc_hi << 32) | rc_lo);
 }
+
+RVLL_HD void sincos_f64(double x, double& s_out, double& c_out) { sincos_f64(x, s_out, c_out, sincos_consts()); }
 
 // n / d by reciprocal refinement.  v_rcp_f64 is accurate to 2^-24.4 (measured, scripts/rcp_probe.py): one
 // Newton step gives 2^-48, and the quotient with one residual correction q + (n - d q) y is then the

@@ -287,8 +287,13 @@ __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx&
                 // Newton, trueanomaly.c:17-33 — op-by-op, no contraction
                 double E = M, s, c, dE;
                 int steps = 0;
+#ifdef RVLL_LOCAL_CONSTS
+                const SincosConsts kc = sincos_consts_pinned();     // loaded here, live through the loop (rvll_math.h)
+#else
+                const SincosConsts kc = sincos_consts();
+#endif
                 do {
-                    sincos_f64(E, s, c);
+                    sincos_f64(E, s, c, kc);
                     const double f  = E - ec * s - M;
                     const double fp = 1 - ec * c;
                     const double En = E - div_exact(f, fp);            // == f / fp, correctly rounded
@@ -460,13 +465,17 @@ __device__ RVLL_DECODE_INLINE void tile_decode(const LoglikeArgs& __restrict__ a
         const int pl = wk / a.Np;
         const int k  = wk - pl * a.Np;
         const double* th = L.theta_s + pl * a.D;
-        const rvll_planet& d = lp[k];
-        const double kraw = slot_lds(&d.k, th);
-        const double praw = slot_lds(&d.p, th);
+        // All six slots first (one 16-byte LDS read each), then the six theta values they point at: two LDS round
+        // trips instead of twelve dependent ones — measured, the slot reads were 1900 of the decode's 2800 cycles.
+        const rvll_planet d = lp[k];
+        const double tk = th[max(d.k.idx, 0)], tp = th[max(d.p.idx, 0)], t1 = th[max(d.e1.idx, 0)],
+                     t2 = th[max(d.e2.idx, 0)], ta = th[max(d.anom.idx, 0)], te = th[max(d.epoch.idx, 0)];
+        const double kraw = d.k.idx >= 0 ? tk : d.k.val;
+        const double praw = d.p.idx >= 0 ? tp : d.p.val;
         const double K = d.k_kind == RVLL_K_LOGK1 ? exp(kraw) : kraw;
         const double Pd = d.p_kind == RVLL_P_LOGPERIOD ? exp(praw) : praw;
-        const double e1 = slot_lds(&d.e1, th);
-        const double e2 = slot_lds(&d.e2, th);
+        const double e1 = d.e1.idx >= 0 ? t1 : d.e1.val;
+        const double e2 = d.e2.idx >= 0 ? t2 : d.e2.val;
         double ecc, omega;
         if (d.ecc_kind == RVLL_ECC_SECOS_SESIN) {
             ecc = e1 * e1 + e2 * e2;
@@ -480,7 +489,7 @@ __device__ RVLL_DECODE_INLINE void tile_decode(const LoglikeArgs& __restrict__ a
             ecc = e1;
             omega = e2;
         }
-        const double anom = slot_lds(&d.anom, th);
+        const double anom = d.anom.idx >= 0 ? ta : d.anom.val;
         const double ma0 = d.anom_kind == RVLL_ANOM_ML0 ? anom - omega : anom;
         const double ec = ecc > 0.99 ? 0.99 : ecc;                  // trueanomaly.c:11-12
         double so, co;
@@ -488,7 +497,7 @@ __device__ RVLL_DECODE_INLINE void tile_decode(const LoglikeArgs& __restrict__ a
         const double q = sqrt((1. - ec) * (1. + ec));
         double* P = L.pp + (pl * a.Np + k) * kPlanetFields;
         P[0] = kTwoPi / Pd;
-        P[1] = slot_lds(&d.epoch, th);
+        P[1] = d.epoch.idx >= 0 ? te : d.epoch.val;
         P[2] = ma0;
         P[3] = ec;
         P[4] = K * co;

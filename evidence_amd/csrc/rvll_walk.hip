@@ -6,6 +6,7 @@
 // they are used instead takes 117 VGPRs with nothing spilled: 4 waves per SIMD.  (For the batch kernels the same
 // flag would put ~30 extra scalar moves into every Newton iteration, enough to saturate the CU's one scalar unit;
 // they keep the default.)
+#define RVLL_LOCAL_CONSTS 1      // the Newton loop's constants are loaded in front of it, not inside it (rvll_math.h)
 #include "rvll_tile.h"
 
 namespace rvll {
