@@ -189,7 +189,7 @@ class Watchdog:
             if self.rank == 0:
                 if self.fallback_line is not None:
                     line = dict(self.fallback_line)
-                    line["config"] = dict(line["config"], note=f"multi-lane phase '{self.phase}' hung; single-lane measurement reported")
+                    line["config"] = dict(line["config"], note=f"phase '{self.phase}' hung; the last completed measurement is reported")
                     print(json.dumps(line), flush=True)
                     code = 0
                 elif self.hung_line is not None:
@@ -438,46 +438,28 @@ def run_single(args, w, model, theta, B):
 
 def run_multi(args, w, model, theta, B, rank, world):
     """N > 1: one rank per GPU.  Order of events, each under the watchdog:
-      1. ranks meet (evidence_amd/rendezvous.py), rank 0's RCCL id goes round, ONE communicator / lane per rank;
+      0. ranks meet (evidence_amd/rendezvous.py); K steps are timed with the gather over the rendezvous sockets (a slower
+         TRANSPORT, the same kernels) before RCCL is touched: the line of last resort;
+      1. rank 0's RCCL id goes round, ONE communicator / lane per rank;
       2. a gathered step is checked (every rank finds its own log-L in its slot, everything finite);
-      3. K steps are timed on one lane (barrier + sync on both sides, max over ranks): a measurement to fall back on;
+      3. K steps are timed on one lane (barrier + sync on both sides, max over ranks): the next line to fall back on;
       4. the ranks try to add pipeline lanes (ncclCommSplit), agree on the minimum, check a gathered step per lane,
          and time K steps again — that is the line reported if it completes and verifies, else the one of step 3.
-    If RCCL cannot be initialised on some rank, all ranks gather the downloaded log-L over the rendezvous sockets
-    instead (a slower TRANSPORT, the same kernels) and say so in config.allgather."""
+    If RCCL cannot be initialised on some rank (or hangs: the watchdog), the line of step 0 is the one reported, and
+    config.allgather says `host-socket-fallback`."""
     from evidence_amd.rendezvous import Rendezvous
     wd = Watchdog(rank, float(os.environ.get("RVLL_WATCHDOG_S", "90")))
     with stdout_to_stderr():
         rdzv = Rendezvous.from_env(timeout=float(os.environ.get("RVLL_RDZV_TIMEOUT_S", "120")))
-    wd.kick("communicator")
+    wd.kick("socket transport")
     if rank == 0:
         wd.hung_line = {"metric": "live_point_logL_evals_per_sec", "value": 0.0, "unit": "evals/s", "n_gpus": world,
                         "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
                         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                         "config": {"workload": WORKLOAD_TEXT[args.config].format(b=B), "cfg": args.config,
                                    "parallelism": f"live-point shards x{world}"}}
-    ok, uid = 1, None
-    with stdout_to_stderr():
-        if rank == 0:
-            try:
-                uid = GpuRVModel.comm_unique_id()
-            except Exception as exc:                  # noqa: BLE001 - reported, then the transport falls back
-                print(f"[rank {rank}] RCCL unavailable: {exc}", file=sys.stderr)
-        uid = rdzv.broadcast(uid, src=0)
-        wd.kick()
-        if uid is None:
-            ok = 0
-        else:
-            try:
-                model.comm_init(uid, world, rank)
-            except Exception as exc:                  # noqa: BLE001
-                ok = 0
-                print(f"[rank {rank}] rvll_comm_init failed: {exc}", file=sys.stderr)
-    gather = "rccl" if rdzv.allreduce(ok, "min") == 1 else "host-socket-fallback"
-    if gather != "rccl" and ok:
-        model.comm_destroy()
-    wd.kick("first gathered step")
     host_all = [None]
+    gather = "host-socket-fallback"
 
     def step():
         model.dev_loglike(B)
@@ -519,14 +501,46 @@ def run_multi(args, w, model, theta, B, rank, world):
     for _ in range(300):                             # untimed pre-warm (clocks), as in the N = 1 run
         model.dev_loglike(B)
     model.dev_sync()
+    # 0. Before RCCL is touched at all: the same K steps with the gather over the rendezvous sockets.  Slower transport,
+    #    same kernels - it exists so that a communicator that hangs in its set-up still leaves a measured line.
     step()
     if not verified():
-        raise SystemExit(f"[rank {rank}] bench.py: the gathered log-L does not match the ranks' own values")
-    elapsed, lanes = timed("one lane"), 1
-    single = None
+        raise SystemExit(f"[rank {rank}] bench.py: the gathered log-L does not match the ranks' own values (sockets)")
+    el_sock = timed("socket transport")
     if rank == 0:
-        single, _, _ = build_line(args, w, model, B, world, elapsed, gather, 1, None)
-        wd.fallback_line = single
+        wd.fallback_line, _, _ = build_line(args, w, model, B, world, el_sock, gather, 1, None)
+
+    wd.kick("communicator")
+    ok, uid = 1, None
+    with stdout_to_stderr():
+        if rank == 0:
+            try:
+                uid = GpuRVModel.comm_unique_id()
+            except Exception as exc:                  # noqa: BLE001 - reported, then the transport falls back
+                print(f"[rank {rank}] RCCL unavailable: {exc}", file=sys.stderr)
+        uid = rdzv.broadcast(uid, src=0)
+        wd.kick()
+        if uid is None:
+            ok = 0
+        else:
+            try:
+                model.comm_init(uid, world, rank)
+            except Exception as exc:                  # noqa: BLE001
+                ok = 0
+                print(f"[rank {rank}] rvll_comm_init failed: {exc}", file=sys.stderr)
+    gather = "rccl" if rdzv.allreduce(ok, "min") == 1 else "host-socket-fallback"
+    if gather != "rccl" and ok:
+        model.comm_destroy()
+    elapsed, lanes, single = el_sock, 1, wd.fallback_line
+    if gather == "rccl":
+        wd.kick("first gathered step over RCCL")
+        step()
+        if not verified():
+            raise SystemExit(f"[rank {rank}] bench.py: the gathered log-L does not match the ranks' own values")
+        elapsed = timed("one lane")
+        if rank == 0:
+            single, _, _ = build_line(args, w, model, B, world, elapsed, gather, 1, None)
+            wd.fallback_line = single
     want = int(os.environ.get("RVLL_LANES", "3"))
     if gather == "rccl" and want > 1:
         wd.kick("adding pipeline lanes")
