@@ -49,3 +49,32 @@ def test_pmc_traffic_record_is_stamped_with_the_kernel_sources_it_was_measured_w
     monkeypatch.setattr(bench, "kernel_source_sha", lambda: "0" * 16)
     got, why = bench.pmc_traffic(rec["cfg"], rec["batch"])
     assert got is None and "stale" in why
+
+
+WATCHDOG_CHILD = """
+import importlib.util, json, sys, time
+spec = importlib.util.spec_from_file_location("bench_module", {bench!r})
+bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+wd = bench.Watchdog(0, 0.3)
+wd.hung_line = {{"metric": "m", "value": 0.0, "config": {{"workload": "w"}}}}
+if {with_fallback}:
+    wd.fallback_line = {{"metric": "m", "value": 5.0, "config": {{"workload": "w", "allgather": "host-socket-fallback"}}}}
+wd.kick("communicator")
+time.sleep(30)                                   # a collective that never returns
+"""
+
+
+def test_watchdog_reports_the_last_completed_measurement_and_leaves():
+    # a phase that hangs after a measurement completed: that line goes out (with the phase named), exit code 0
+    code = WATCHDOG_CHILD.format(bench=str(REPO / "bench.py"), with_fallback=True)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["value"] == 5.0 and "communicator" in line["config"]["note"]
+    assert "no progress" in r.stderr
+    # nothing completed: the line says so (value 0, rccl-hung) and the exit code is non-zero
+    code = WATCHDOG_CHILD.format(bench=str(REPO / "bench.py"), with_fallback=False)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 3
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["value"] == 0.0 and line["config"]["allgather"] == "rccl-hung" and line["config"]["hung_phase"] == "communicator"
