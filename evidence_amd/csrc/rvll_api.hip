@@ -152,6 +152,7 @@ void dev_free(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
 constexpr int kMaxLanes = 4;
 // rvll_loglike_batch: host batches from kSplitMinPoints on go up in overlapped chunks of about kSplitChunkPoints
 constexpr long long kSplitMinPoints = 16384, kSplitChunkPoints = 16384, kSplitMaxChunks = 8;   // profiles/r02_split_probe.txt
+constexpr int kWalkWords = 8;                 // counters of the walk kernel: calls, tile slots, 4 phase bins + workgroups (diagnostic build)
 constexpr long long kFusedMaxPoints = 4096;   // rvll_prior_loglike_batch: one launch up to here, two beyond
 
 struct rvll_handle {
@@ -228,6 +229,9 @@ struct rvll_handle {
     int32_t* d_walk_wrapped = nullptr;
     unsigned long long* d_walk_ncalls = nullptr;
     int32_t *d_walk_steps = nullptr, *d_walk_wid = nullptr, *d_walk_start = nullptr;   // [walk_cap] each
+    int walk_spec = 4;                          // candidates a walker may evaluate ahead per iteration (rvll_set_walk_speculation)
+    long long walk_evaluated = 0;               // tile slots the last rvll_slice_walk evaluated (>= its ncalls)
+    unsigned long long walk_phase[5] = {};      // diagnostic build (make walktrace): 100 MHz ticks per phase, summed over workgroups; workgroups
 
     hipEvent_t marks[2] = {nullptr, nullptr};   // rvll_dev_mark: HIP events on lane 0's stream
 
@@ -1453,7 +1457,7 @@ int rvll_slice_walk(rvll_handle* h, double* cube, double* theta, double* logl, i
         if (!h->d_walk_chol) {
             HIP_TRY(hipMalloc(&h->d_walk_chol, sizeof(double) * D * D));
             HIP_TRY(hipMalloc(&h->d_walk_wrapped, sizeof(int32_t) * D));
-            HIP_TRY(hipMalloc(&h->d_walk_ncalls, sizeof(unsigned long long)));
+            HIP_TRY(hipMalloc(&h->d_walk_ncalls, kWalkWords * sizeof(unsigned long long)));   // calls used, tile slots evaluated, diagnostic bins
         }
         h->walk_cap = (long long)cap;
     }
@@ -1465,7 +1469,7 @@ int rvll_slice_walk(rvll_handle* h, double* cube, double* theta, double* logl, i
     HIP_TRY(hipMemcpyAsync(h->d_walk_logl, logl, sizeof(double) * (size_t)K, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(h->d_walk_chol, chol, sizeof(double) * D * D, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(h->d_walk_wrapped, wr.data(), sizeof(int32_t) * D, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(h->d_walk_ncalls, 0, sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(h->d_walk_ncalls, 0, kWalkWords * sizeof(unsigned long long), st));
     HIP_TRY(hipStreamSynchronize(st));                 // wr (and pageable sources) may go out of scope
 
     // the walk keeps per-walker state in LDS next to the tile's carve: shrink the group until both fit
@@ -1489,18 +1493,25 @@ int rvll_slice_walk(rvll_handle* h, double* cube, double* theta, double* logl, i
     // Slim walk (verified-table quantiles only, 4 waves per SIMD) when every Beta / Gamma prior has such a table;
     // walkers it could not finish come back with steps_done < nsteps and are finished by the fat kernel below.
     const bool slim = h->all_direct && !getenv("RVLL_WALK_FAT");
+    int spec = h->walk_spec;
+    if (const char* e = getenv("RVLL_WALK_SPEC")) spec = atoi(e);       // measurement switch (1: no speculation)
+    spec = std::max(1, std::min(spec, rvll::kMaxPointsPerBlock));
     rvll::WalkArgs w{h->d_walk_u, h->d_walk_theta, h->d_walk_logl, h->d_walk_chol, h->d_walk_wrapped, (long long)K,
                      nsteps, max_rounds, (unsigned long long)seed, lstar, h->d_walk_ncalls,
-                     h->d_walk_steps, nullptr, nullptr, (long long)walker_base};
+                     h->d_walk_steps, nullptr, nullptr, (long long)walker_base, spec, h->d_walk_ncalls + 1};
     HIP_TRY(rvll::launch_slice_walk(a, w, !slim, st));
-    unsigned long long n = 0;
+    unsigned long long n = 0, evaluated[kWalkWords] = {};
+    h->walk_evaluated = 0;
     std::vector<int32_t> steps(slim ? (size_t)K : 0);
     HIP_TRY(hipMemcpyAsync(cube, h->d_walk_u, sizeof(double) * D * (size_t)K, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(theta, h->d_walk_theta, sizeof(double) * D * (size_t)K, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(logl, h->d_walk_logl, sizeof(double) * (size_t)K, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(&n, h->d_walk_ncalls, sizeof n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(evaluated, h->d_walk_ncalls, sizeof evaluated, hipMemcpyDeviceToHost, st));
     if (slim) HIP_TRY(hipMemcpyAsync(steps.data(), h->d_walk_steps, sizeof(int32_t) * (size_t)K, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    n = evaluated[0];
+    h->walk_evaluated = (long long)evaluated[1];
+    for (int k = 0; k < 5; ++k) h->walk_phase[k] = evaluated[2 + k];
     unsigned long long total = n;
     if (slim) {
         std::vector<int32_t> ids, start;
@@ -1521,7 +1532,7 @@ int rvll_slice_walk(rvll_handle* h, double* cube, double* theta, double* logl, i
             HIP_TRY(hipMemcpyAsync(h->d_walk_logl, sl.data(), sizeof(double) * M, hipMemcpyHostToDevice, st));
             HIP_TRY(hipMemcpyAsync(h->d_walk_wid, ids.data(), sizeof(int32_t) * M, hipMemcpyHostToDevice, st));
             HIP_TRY(hipMemcpyAsync(h->d_walk_start, start.data(), sizeof(int32_t) * M, hipMemcpyHostToDevice, st));
-            HIP_TRY(hipMemsetAsync(h->d_walk_ncalls, 0, sizeof(unsigned long long), st));
+            HIP_TRY(hipMemsetAsync(h->d_walk_ncalls, 0, 2 * sizeof(unsigned long long), st));   // the diagnostic bins keep adding up
             rvll::LoglikeArgs a2;
             rc = walk_args((long long)M, &a2);
             if (rc) return rc;
@@ -1533,9 +1544,11 @@ int rvll_slice_walk(rvll_handle* h, double* cube, double* theta, double* logl, i
             HIP_TRY(hipMemcpyAsync(su.data(), h->d_walk_u, sizeof(double) * D * M, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipMemcpyAsync(sth.data(), h->d_walk_theta, sizeof(double) * D * M, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipMemcpyAsync(sl.data(), h->d_walk_logl, sizeof(double) * M, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(&n, h->d_walk_ncalls, sizeof n, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(evaluated, h->d_walk_ncalls, sizeof evaluated, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
-            total += n;
+            total += evaluated[0];
+            h->walk_evaluated += (long long)evaluated[1];
+            for (int k = 0; k < 5; ++k) h->walk_phase[k] = evaluated[2 + k];
             for (size_t j = 0; j < M; ++j) {
                 memcpy(cube + (size_t)ids[j] * D, &su[j * D], sizeof(double) * D);
                 memcpy(theta + (size_t)ids[j] * D, &sth[j * D], sizeof(double) * D);
@@ -1545,6 +1558,29 @@ int rvll_slice_walk(rvll_handle* h, double* cube, double* theta, double* logl, i
     }
     if (ncalls) *ncalls = (int64_t)total;
     h->theta_async = false;
+    return RVLL_OK;
+}
+
+int rvll_set_walk_speculation(rvll_handle* h, int32_t max_ahead)
+{
+    if (!h) return fail(RVLL_E_INVALID, "null handle");
+    if (max_ahead < 1 || max_ahead > rvll::kMaxPointsPerBlock)
+        return fail(RVLL_E_INVALID, "max_ahead must be in [1, %d]", rvll::kMaxPointsPerBlock);
+    h->walk_spec = max_ahead;
+    return RVLL_OK;
+}
+
+int rvll_slice_walk_evaluated(rvll_handle* h, int64_t* evaluated)
+{
+    if (!h || !evaluated) return fail(RVLL_E_INVALID, "null argument");
+    *evaluated = h->walk_evaluated;
+    return RVLL_OK;
+}
+
+int rvll_slice_walk_phases(rvll_handle* h, uint64_t out[5])
+{
+    if (!h || !out) return fail(RVLL_E_INVALID, "null argument");
+    for (int k = 0; k < 5; ++k) out[k] = h->walk_phase[k];
     return RVLL_OK;
 }
 

@@ -97,7 +97,11 @@ struct WalkArgs {
     const int32_t* step_start; // [K] or null: move to resume at (default 0)
     long long walker_base;     // added to the row (or to walker_id) in the random-number counters: a shard of a larger
                                // set of walkers draws exactly what the unsharded walk would draw for its rows
+    int spec_max;              // candidates evaluated AHEAD per walker and iteration when the workgroup's tile has free
+                               // slots (1: none): candidate r+1 is the one the walker draws if candidate r is rejected
+    unsigned long long* nslots;   // or null: += tile slots evaluated (>= ncalls: includes speculative ones that went unused)
 };
+constexpr int kWalkCholLds = 48;   // the walk stages a whitening factor of up to 48 x 48 (18 KB) in LDS
 size_t walk_lds_bytes(const LoglikeArgs& a);
 // a: fused (cube -> theta -> log-L) arguments whose cube / theta_out / logL / flags rows [0, K) are scratch
 // fat = false: slim prior stage (4 waves per SIMD; deferring walkers report steps_done < nsteps);

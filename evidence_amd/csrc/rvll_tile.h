@@ -404,7 +404,7 @@ __device__ __forceinline__ TileLds tile_views(const LoglikeArgs& a, double* smem
 //    then the iterative kinds compacted so that consecutive lanes all run a solve); theta is written back.
 template <int FUSED, int NT>
 __device__ __forceinline__ void tile_stage(const LoglikeArgs& __restrict__ a, const TileLds& L, long long p0, int npts,
-                                           unsigned long long* stamp = nullptr)
+                                           unsigned long long* stamp = nullptr, const double* cube_rows = nullptr)
 {
     const int tid = threadIdx.x;
     for (int i = tid; i < npts; i += NT) { L.acc[i] = 0.; L.pflags[i] = 0; L.anyfail[i] = 0; }
@@ -412,7 +412,8 @@ __device__ __forceinline__ void tile_stage(const LoglikeArgs& __restrict__ a, co
     if (tid == 0) { L.nfail[0] = 0; L.ticket[0] = 0; }
     if constexpr (FUSED == kFusedSlim) __syncthreads();          // deferrals are OR-ed into pflags below
     if constexpr (FUSED != kFusedNone) {
-        const double* src = a.cube + p0 * a.D;
+        // cube_rows: the tile's unit-cube rows where the caller already holds them (the walk: in LDS), else a.cube
+        const double* src = cube_rows ? cube_rows : a.cube + p0 * a.D;
         double* dst = a.theta_out + p0 * a.D;
         for (int i = tid; i < npts * a.D; i += NT) {
             const int pl = i / a.D, d = i - pl * a.D;
@@ -556,12 +557,19 @@ __device__ __forceinline__ void point_partials4(const double* contrib, int base,
 }
 
 // 4. one log-L per live point
-__device__ __forceinline__ void tile_write_point(const LoglikeArgs& __restrict__ a, const TileLds& L, long long p0, int pl)
+// (the walk reads a finished tile's results through this, straight from LDS)
+__device__ __forceinline__ double tile_point_result(const LoglikeArgs& __restrict__ a, const TileLds& L, int pl, int& flags)
 {
     int f = L.pflags[pl];
     if (L.anyfail[pl]) f |= RVLL_FLAG_NONCONVERGED;
+    flags = f;
     const bool invalid = (f & RVLL_FLAG_INVALID_ORBIT) != 0 && a.Np > 0;
-    a.logL[p0 + pl] = invalid ? -1e30 : a.cte - L.acc[pl];                 // rvmodel:203, :78-80
+    return invalid ? -1e30 : a.cte - L.acc[pl];                            // rvmodel:203, :78-80
+}
+__device__ __forceinline__ void tile_write_point(const LoglikeArgs& __restrict__ a, const TileLds& L, long long p0, int pl)
+{
+    int f;
+    a.logL[p0 + pl] = tile_point_result(a, L, pl, f);
     if (a.flags) a.flags[p0 + pl] = f;
 }
 
@@ -583,7 +591,8 @@ __device__ __forceinline__ void tile_write_point(const LoglikeArgs& __restrict__
 // TRACE: diagnostic build (launch_loglike_trace) — a few s_memrealtime stamps per workgroup go to a.trace, a
 // buffer nothing else reads; no stamp executes in the product kernels.
 template <int PREC, int FUSED, bool TRACE = false, int NT = kThreads, bool DYN = false>
-__device__ __forceinline__ __attribute__((flatten)) void loglike_tile(const LoglikeArgs& __restrict__ a, double* __restrict__ smem, long long p0, int npts)
+__device__ __forceinline__ __attribute__((flatten)) void loglike_tile(const LoglikeArgs& __restrict__ a, double* __restrict__ smem, long long p0, int npts,
+                                                                      const double* cube_rows = nullptr)
 {
     unsigned long long* tr = nullptr;
     if constexpr (TRACE) {
@@ -606,7 +615,7 @@ __device__ __forceinline__ __attribute__((flatten)) void loglike_tile(const Logl
     // only the issue slots older ones leave (arbitration is by priority, then age), which stretched it 2.5x next
     // to three workgroups in their item loops: run it at raised priority, the item loop at the default.
     if constexpr (!DYN) __builtin_amdgcn_s_setprio(3);
-    tile_stage<FUSED, NT>(a, L, p0, npts, TRACE && DYN ? tr + 1 : nullptr);
+    tile_stage<FUSED, NT>(a, L, p0, npts, TRACE && DYN ? tr + 1 : nullptr, cube_rows);
     __syncthreads();
     if constexpr (TRACE && DYN) { if (tid == 0) tr[2] = __builtin_amdgcn_s_memrealtime(); }
     tile_decode<NT>(a, L, npts);

@@ -23,6 +23,15 @@ namespace {
 // iteration — so the tile stays full until the walkers run out of moves (their totals over nsteps moves are
 // close), instead of idling behind the slowest walker of every move.  Trip counts are bounded by
 // nsteps * max_rounds and shared through LDS, so all waves loop alike.
+// SPECULATION.  The moves of a walker are a chain of dependent evaluations, and chains differ a lot in length (a
+// walker in a narrow mode shrinks its bracket many more times per move): towards the end of a workgroup's life most
+// of its tile is empty while the last walkers crawl on, one candidate per iteration.  Free tile slots are therefore
+// given to the walkers that are left: a walker with S slots evaluates candidates r, r+1, .. r+S-1 of its move in ONE
+// iteration, where candidate r+j is exactly the one it would draw in round r+j if r .. r+j-1 are all rejected (the
+// bracket after a rejection is known before the rejection is: it ends at the rejected candidate).  The results are
+// then consumed in order — accept the first one above lstar, shrink past the others — so positions, log-L, counters
+// and ncalls are bit for bit those of the one-candidate-per-iteration walk, whatever the workgroup geometry; only
+// the iterations a slow walker needs drop (nslots counts what was evaluated, ncalls what was used).
 // FAT = false: the prior stage evaluates Beta / Gamma quantiles by their verified tables only (rvll_tile.h,
 // prior_heavy_slim).  A walker whose candidate needs anything else stops at the START of that move and reports the
 // number of completed moves in steps_done; the host finishes those walkers with the FAT instantiation (full solvers
@@ -44,34 +53,72 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
     double* hi_s = lo_s + PB * D;
     double* tmin = hi_s + PB * D;                          // [PB]
     double* tmax = tmin + PB;
-    double* tcur = tmax + PB;
-    double* wl   = tcur + PB;
-    int* act     = reinterpret_cast<int*>(wl + PB);         // [PB] walkers with moves left (local index), compacted
-    int* state   = act + PB;                                // [PB] 0: needs a new direction, 1: in a move, 2: accepted just now, 3: deferred
+    double* slot_t = tmax + PB;                            // [PB] per tile slot: position along its walker's direction
+    double* wl   = slot_t + PB;
+    double* cand = wl + PB;                                // [PB][D] per tile slot: the candidate's unit-cube row
+    const bool chol_in_lds = D <= kWalkCholLds;
+    double* chol_s = cand + PB * D;                        // [D][D] the whitening factor, when it is small enough to stage
+    int* act     = reinterpret_cast<int*>(chol_s + (chol_in_lds ? D * D : 0));   // [2][PB] walkers with moves left (local index),
+                                                            // compacted; the list of the next iteration is written while this one's is read
+    int* state   = act + 2 * PB;                              // [PB] 0: needs a new direction, 1: in a move, 2: accepted just now, 3: deferred
     int* step_of = state + PB;                              // [PB] moves completed
     int* round_of = step_of + PB;                           // [PB] candidates tried in the current move
-    int* nact_s  = round_of + PB;                           // [1]
+    int* first_of = round_of + PB;                          // [PB] per walker: its first tile slot of this iteration ...
+    int* nsp_of  = first_of + PB;                           // [PB] ... and how many it has (>= 1)
+    int* acc_slot = nsp_of + PB;                            // [PB] per walker: the slot whose candidate was accepted
+    int* used_of = acc_slot + PB;                           // [PB] per walker: candidates consumed this iteration
+    int* slot_pl = used_of + PB;                            // [PB] per tile slot: its walker
+    int* nact_s  = slot_pl + PB;                            // [2]  active walkers, tile slots of this iteration
+    int* wrapped_s = nact_s + 2;                            // [D]  circular parameters
+    const double* chol = chol_in_lds ? chol_s : w.chol;
+    const TileLds L = tile_views(a, smem);                  // the tile's results are read back from LDS (tile_point_result)
     const double one_below = 0.99999999999999988898;        // nextafter(1, 0)
 
     for (int i = tid; i < nw * D; i += kThreads) wu[i] = w.u[w0 * D + i];
+    if (chol_in_lds) for (int i = tid; i < D * D; i += kThreads) chol_s[i] = w.chol[i];
+    for (int i = tid; i < D; i += kThreads) wrapped_s[i] = w.wrapped[i];
     for (int i = tid; i < nw; i += kThreads) {
         wl[i] = w.logl[w0 + i]; state[i] = 0; round_of[i] = 0;
         step_of[i] = w.step_start ? w.step_start[w0 + i] : 0;
     }
     __syncthreads();
-    if (tid == 0) {                                         // walkers that still have moves to make
+    // tile slots of the next iteration (thread 0): every active walker one, the free ones dealt out evenly, at most
+    // spec_max per walker and never past the move's last round
+    auto deal_slots = [&](const int* act, int n) {
+        const int base = n ? nw / n : 0, rem = n ? nw % n : 0;
+        int f = 0;
+        for (int ai = 0; ai < n; ++ai) {
+            const int pl = act[ai];
+            int S = min(w.spec_max, base + (ai < rem ? 1 : 0));
+            S = max(1, min(S, w.max_rounds - (state[pl] == 0 ? 0 : round_of[pl])));
+            first_of[pl] = f; nsp_of[pl] = S; f += S;
+        }
+        nact_s[0] = n; nact_s[1] = f;
+    };
+    if (tid == kThreads - 1) {                              // walkers that still have moves to make (the bookkeeping thread)
         int n = 0;
         for (int i = 0; i < nw; ++i) if (step_of[i] < w.nsteps) act[n++] = i;
-        nact_s[0] = n;
+        deal_slots(act, n);
     }
-    unsigned long long calls = 0;                           // thread 0 only
+    int* const act0 = act;
+    unsigned long long calls = 0, slots = 0;                // the bookkeeping thread only
     __syncthreads();
 
+    // phase clock of a diagnostic build (make walktrace; scripts/walk_phase_probe.py): thread 0 sums the time between
+    // barriers into four bins — directions and chord limits / candidates / prior transform + log-L tile / accept + copy
+#ifdef RVLL_WALK_TRACE
+    unsigned long long ph[5] = {0, 0, 0, 0, 0}, last = __builtin_amdgcn_s_memrealtime();
+#define WALK_STAMP(k) do { if (tid == 0) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); ph[k] += now - last; last = now; } } while (0)
+#else
+#define WALK_STAMP(k) do { } while (0)
+#endif
     const long long max_iters = (long long)w.nsteps * w.max_rounds;
     for (long long iter = 0; iter < max_iters; ++iter) {
-        const int nact = nact_s[0];
+        const int nact = nact_s[0], nslots = nact_s[1];
         if (nact == 0) break;
-        // walkers starting a move: standard normals (Box-Muller on two counter-based uniforms) ...
+        act = act0 + (iter & 1) * PB;
+        int* const act_next = act0 + ((iter + 1) & 1) * PB;
+        // walkers starting a move: standard normals (Box-Muller on two counter-based uniforms), parked in lo_s ...
         for (int i = tid; i < nact * D; i += kThreads) {
             const int pl = act[i / D], k = i % D;
             if (state[pl] != 0) continue;
@@ -80,45 +127,30 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
             const double u1 = uniform01(w.seed, ctr), u2 = uniform01(w.seed, ctr + 1);
             double sn, cs;
             sincos_f64(kTwoPi * u2, sn, cs);
-            dir[pl * D + k] = sqrt(-2. * log(1. - u1)) * cs;
+            lo_s[pl * D + k] = sqrt(-2. * log(1. - u1)) * cs;
         }
         __syncthreads();
-        // ... direction = chol * z (lower triangular; held in registers until every z has been read) ...
-        double mine[4];                                     // PB * D <= 4 * kThreads
-        int cnt = 0;
-        for (int i = tid; i < nact * D; i += kThreads, ++cnt) {
-            const int pl = act[i / D], k = i % D;
-            if (state[pl] != 0) continue;
-            double acc = 0.;
-            for (int j = 0; j <= k; ++j) acc += w.chol[k * D + j] * dir[pl * D + j];
-            mine[cnt & 3] = acc;
-        }
-        __syncthreads();
-        cnt = 0;
-        for (int i = tid; i < nact * D; i += kThreads, ++cnt) {
-            const int pl = act[i / D], k = i % D;
-            if (state[pl] == 0) dir[pl * D + k] = mine[cnt & 3];
-        }
-        __syncthreads();
-        // ... normalise: 1 / |dir| per walker (parked in tmin until the chord is known) ...
-        for (int ai = tid; ai < nact; ai += kThreads) {
-            const int pl = act[ai];
-            if (state[pl] != 0) continue;
-            double n2 = 0.;
-            for (int k = 0; k < D; ++k) n2 += dir[pl * D + k] * dir[pl * D + k];
-            tmin[pl] = 1. / sqrt(n2);
-        }
-        __syncthreads();
-        // ... unit direction and the chord limits of every coordinate, one lane per (walker, coordinate): the two
-        // divisions per coordinate used to run serially in ONE lane per walker ...
+        // ... direction = chol * z (lower triangular), parked in the candidate rows, which are free until the tile ...
         for (int i = tid; i < nact * D; i += kThreads) {
             const int pl = act[i / D], k = i % D;
             if (state[pl] != 0) continue;
-            const double d = dir[pl * D + k] * tmin[pl], u = wu[pl * D + k];
+            double acc = 0.;
+            for (int j = 0; j <= k; ++j) acc += chol[k * D + j] * lo_s[pl * D + j];
+            cand[pl * D + k] = acc;
+        }
+        __syncthreads();
+        // ... unit direction and the chord limits of every coordinate, one lane per (walker, coordinate); every lane
+        // sums the walker's norm itself (same order, same bits) rather than wait a barrier for one lane to do it ...
+        for (int i = tid; i < nact * D; i += kThreads) {
+            const int pl = act[i / D], k = i % D;
+            if (state[pl] != 0) continue;
+            double n2 = 0.;
+            for (int j = 0; j < D; ++j) n2 += cand[pl * D + j] * cand[pl * D + j];
+            const double d = cand[pl * D + k] * (1. / sqrt(n2)), u = wu[pl * D + k];
             dir[pl * D + k] = d;
             double lo = -INFINITY, hi = INFINITY;
             if (d != 0.) {
-                if (w.wrapped[k]) {
+                if (wrapped_s[k]) {
                     const double half = 0.5 / fabs(d);
                     lo = -half; hi = half;
                 } else {
@@ -129,6 +161,7 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
             lo_s[pl * D + k] = lo; hi_s[pl * D + k] = hi;
         }
         __syncthreads();
+        WALK_STAMP(0);
         // ... the chord (same max / min sequence over the coordinates as before); then the candidate position along it
         for (int ai = tid; ai < nact; ai += kThreads) {
             const int pl = act[ai];
@@ -139,54 +172,87 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
                 round_of[pl] = 0;
                 state[pl] = 1;
             }
+            // this round's candidate and, in the walker's further slots, the ones the next rounds draw if it is rejected
             const unsigned long long wid = (unsigned long long)(w.walker_base + (w.walker_id ? (long long)w.walker_id[w0 + pl] : w0 + pl));
             const unsigned long long ctr = (wid << 32) | ((unsigned long long)step_of[pl] << 14) | (unsigned)(8192 + round_of[pl]);
-            tcur[pl] = tmin[pl] + (tmax[pl] - tmin[pl]) * uniform01(w.seed, ctr);
-        }
-        __syncthreads();
-        double* crow = const_cast<double*>(a.cube) + w0 * D;           // this workgroup's scratch rows
-        for (int i = tid; i < nact * D; i += kThreads) {
-            const int ai = i / D, k = i - ai * D, pl = act[ai];
-            double c = wu[pl * D + k] + tcur[pl] * dir[pl * D + k];
-            if (w.wrapped[k]) c -= floor(c);
-            crow[ai * D + k] = fmin(fmax(c, 0.), one_below);
-        }
-        __syncthreads();
-        loglike_tile<PREC, FAT ? kFusedFull : kFusedSlim>(a, smem, w0, nact);   // prior transform + log-L of the candidates
-        __syncthreads();
-        for (int ai = tid; ai < nact; ai += kThreads) {
-            const int pl = act[ai];
-            const double cl = a.logL[w0 + ai];
-            if (!FAT && (a.flags[w0 + ai] & kFlagDeferred)) state[pl] = 3;      // leave at the start of this move
-            else if (cl > w.lstar) { state[pl] = 2; wl[pl] = cl; }
-            else {
-                if (tcur[pl] < 0.) tmin[pl] = tcur[pl]; else tmax[pl] = tcur[pl];
-                if (++round_of[pl] >= w.max_rounds) { state[pl] = 0; step_of[pl] += 1; }   // give the move up, stay put
+            double lo = tmin[pl], hi = tmax[pl];
+            const int first = first_of[pl], S = nsp_of[pl];
+            for (int j = 0; j < S; ++j) {
+                const double t = lo + (hi - lo) * uniform01(w.seed, ctr + (unsigned)j);
+                slot_t[first + j] = t; slot_pl[first + j] = pl;
+                if (t < 0.) lo = t; else hi = t;
             }
         }
         __syncthreads();
-        for (int i = tid; i < nact * D; i += kThreads) {
-            const int ai = i / D, k = i - ai * D, pl = act[ai];
-            if (state[pl] != 2) continue;
-            wu[pl * D + k] = crow[ai * D + k];
-            w.theta[(w0 + pl) * D + k] = a.theta_out[(w0 + ai) * D + k];
+        for (int i = tid; i < nslots * D; i += kThreads) {
+            const int sl = i / D, k = i - sl * D, pl = slot_pl[sl];
+            double c = wu[pl * D + k] + slot_t[sl] * dir[pl * D + k];
+            if (wrapped_s[k]) c -= floor(c);
+            cand[i] = fmin(fmax(c, 0.), one_below);
         }
         __syncthreads();
-        if (tid == 0) {
-            calls += (unsigned long long)nact;
+        WALK_STAMP(1);
+        // prior transform + log-L of the candidates: rows read from LDS, results left in LDS (and in the scratch rows)
+        loglike_tile<PREC, FAT ? kFusedFull : kFusedSlim>(a, smem, w0, nslots, cand);
+        // the walk's own phases are short and serial (a lane per walker, one thread for the bookkeeping): at the
+        // default priority they get every fourth issue slot next to three workgroups in their item loops and a
+        // barrier-to-barrier phase of ~50 instructions takes 1-2 us (phase clock: 33 % of a workgroup's life for a
+        // few per cent of its instructions).  Raised here, lowered again by the tile in front of its item loop.
+        __builtin_amdgcn_s_setprio(3);
+        __syncthreads();
+        WALK_STAMP(2);
+        for (int ai = tid; ai < nact; ai += kThreads) {
+            const int pl = act[ai];
+            const int first = first_of[pl], S = nsp_of[pl];
+            int used = 0;
+            acc_slot[pl] = -1;
+            for (int j = 0; j < S; ++j) {                               // in the order the walker would have met them
+                int fl;
+                const double cl = tile_point_result(a, L, first + j, fl);
+                used = j + 1;
+                if (!FAT && (fl & kFlagDeferred)) { state[pl] = 3; break; }                        // leave at the start of this move
+                if (cl > w.lstar) { state[pl] = 2; wl[pl] = cl; acc_slot[pl] = first + j; break; }
+                const double t = slot_t[first + j];
+                if (t < 0.) tmin[pl] = t; else tmax[pl] = t;
+                if (++round_of[pl] >= w.max_rounds) { state[pl] = 0; step_of[pl] += 1; break; }     // give the move up, stay put
+            }
+            used_of[pl] = used;
+        }
+        __syncthreads();
+        // accepted rows move in (every thread but the last) while the last thread does the bookkeeping: it writes the
+        // NEXT iteration's list and touches nothing the copy reads
+        for (int i = tid; i < nact * D; i += kThreads) {
+            const int ai = i / D, k = i - ai * D, pl = act[ai];
+            const int sl = acc_slot[pl];
+            if (sl < 0) continue;
+            wu[pl * D + k] = cand[sl * D + k];
+            w.theta[(w0 + pl) * D + k] = L.theta_s[sl * D + k];
+        }
+        if (tid == kThreads - 1) {
+            slots += (unsigned long long)nslots;
             int n = 0;
             for (int ai = 0; ai < nact; ++ai) {
                 const int pl = act[ai];
+                calls += (unsigned long long)used_of[pl];
                 if (state[pl] == 2) { state[pl] = 0; step_of[pl] += 1; }
-                if (step_of[pl] < w.nsteps && state[pl] != 3) act[n++] = pl;
+                if (step_of[pl] < w.nsteps && state[pl] != 3) act_next[n++] = pl;
             }
-            nact_s[0] = n;
+            deal_slots(act_next, n);
         }
         __syncthreads();
+        WALK_STAMP(3);
     }
     for (int i = tid; i < nw * D; i += kThreads) w.u[w0 * D + i] = wu[i];
     for (int i = tid; i < nw; i += kThreads) { w.logl[w0 + i] = wl[i]; if (w.steps_done) w.steps_done[w0 + i] = step_of[i]; }
-    if (tid == 0 && calls) atomicAdd(w.ncalls, calls);
+    if (tid == kThreads - 1 && calls) atomicAdd(w.ncalls, calls);
+    if (tid == kThreads - 1 && slots && w.nslots) atomicAdd(w.nslots, slots);
+#ifdef RVLL_WALK_TRACE
+    if (tid == 0 && w.nslots) {
+        for (int k = 0; k < 4; ++k) atomicAdd(w.nslots + 1 + k, ph[k]);
+        atomicAdd(w.nslots + 5, 1ull);
+    }
+#endif
+#undef WALK_STAMP
 }
 
 }  // namespace
@@ -194,14 +260,15 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
 size_t walk_lds_bytes(const LoglikeArgs& a)
 {
     const size_t base = (loglike_lds_bytes(a) + 15) & ~(size_t)15;
-    return base + sizeof(double) * ((size_t)4 * a.PB * a.D + 4 * a.PB) + sizeof(int) * (4 * a.PB + 2) + 16;
+    return base + sizeof(double) * ((size_t)5 * a.PB * a.D + 4 * a.PB + (a.D <= kWalkCholLds ? a.D * a.D : 0)) +
+           sizeof(int) * (10 * a.PB + 2 + a.D) + 16;
 }
 
 hipError_t launch_slice_walk(const LoglikeArgs& a, const WalkArgs& w, bool fat, hipStream_t stream)
 {
     if (w.K <= 0 || w.nsteps <= 0) return hipSuccess;
     if (!a.cube || !a.theta_out || !a.priors || !a.flags || a.PB * a.D > 4 * kThreads || w.nsteps >= (1 << 18) ||
-        w.max_rounds < 1 || w.max_rounds > 4096 || a.D > 4096 || (!fat && !w.steps_done))
+        w.max_rounds < 1 || w.max_rounds > 4096 || a.D > 4096 || (!fat && !w.steps_done) || w.spec_max < 1)
         return hipErrorInvalidValue;
     const size_t lds = walk_lds_bytes(a);
     if (lds > 64 * 1024) return hipErrorInvalidValue;

@@ -318,6 +318,23 @@ class GpuRVModel:
         """Test hook (include/rvll.h): |logit q| range the table-only prior stage takes before handing over."""
         _abi.check(self._lib.rvll_set_slim_table_range(self._h, float(umax)))
 
+    def set_walk_speculation(self, max_ahead):
+        """Candidates a walker of slice_walk may evaluate ahead per iteration in otherwise free tile slots (include/rvll.h;
+        default 4, 1 = none).  Results do not depend on it."""
+        _abi.check(self._lib.rvll_set_walk_speculation(self._h, int(max_ahead)))
+
+    def slice_walk_evaluated(self):
+        """Tile slots the last slice_walk evaluated (>= the calls it reported: unused speculative candidates included)."""
+        n = C.c_int64(0)
+        _abi.check(self._lib.rvll_slice_walk_evaluated(self._h, C.byref(n)))
+        return int(n.value)
+
+    def slice_walk_phases(self):
+        """Diagnostic library build only (include/rvll.h): ticks per phase of the last slice_walk, summed over workgroups."""
+        out = (C.c_uint64 * 5)()
+        _abi.check(self._lib.rvll_slice_walk_phases(self._h, out))
+        return [int(v) for v in out]
+
     def debug_eval(self, op, x, y=None):
         """Evaluate one device math routine elementwise (include/rvll.h, diagnostics)."""
         x = np.ascontiguousarray(x, dtype=np.float64)

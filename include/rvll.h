@@ -231,6 +231,19 @@ int rvll_prior_loglike_batch(rvll_handle* h, const double* cube, int64_t B,
 int rvll_slice_walk(rvll_handle* h, double* cube, double* theta, double* logl, int64_t K, double lstar,
                     const double* chol, const int32_t* wrapped /*[ndim] or NULL*/, int32_t nsteps,
                     int32_t max_rounds, uint64_t seed, int64_t walker_base, int64_t* ncalls);
+/* A walker's moves are a chain of dependent evaluations; when walkers of a workgroup have finished, the free slots of
+ * its tile evaluate, for the walkers that are left, up to max_ahead candidates of the current move per iteration:
+ * candidate r+1 is the one the walker draws if candidate r is rejected (the shrunk bracket is known in advance), and
+ * the results are consumed in order — so end points, log-L and *ncalls are those of the one-candidate-per-iteration
+ * walk, bit for bit; only the number of iterations drops.  Default 4; 1 switches it off.
+ * rvll_slice_walk_evaluated: tile slots the last rvll_slice_walk evaluated (>= its ncalls: speculative candidates
+ * that went unused are work done, not likelihood calls of the sampler).                                          */
+int rvll_set_walk_speculation(rvll_handle* h, int32_t max_ahead);
+int rvll_slice_walk_evaluated(rvll_handle* h, int64_t* evaluated);
+/* Diagnostic build only (make -C evidence_amd/csrc walktrace; all zeros otherwise): where the workgroups of the last
+ * rvll_slice_walk spent their time — 100 MHz ticks summed over workgroups for [0] directions + chord limits,
+ * [1] candidates, [2] prior transform + log-L tile, [3] accept / copy / bookkeeping; [4] = number of workgroups. */
+int rvll_slice_walk_phases(rvll_handle* h, uint64_t out[5]);
 
 /* ---- scalar-callback latency ------------------------------------------------------------------------- */
 /* PolyChord's loglike(theta) is irreducibly scalar (evidence/polychord/__init__.py:166-171): one theta per call.
