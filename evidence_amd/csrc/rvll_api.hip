@@ -1438,7 +1438,7 @@ int rvll_slice_walk(rvll_handle* h, double* cube, double* theta, double* logl, i
         return fail(RVLL_E_INVALID, "nsteps / max_rounds / K / walker_base out of range");
     const size_t D = (size_t)h->L.ndim;
     if (D < 1) return fail(RVLL_E_INVALID, "no free parameter to walk in");
-    rc = rvll_dev_reserve(h, K);                       // scratch rows: d_cube, d_theta, log-L / flags of lane 0
+    rc = rvll_dev_reserve(h, K + rvll::kMaxPointsPerBlock);   // scratch rows (one tile per workgroup): d_theta, log-L / flags of lane 0
     if (rc) return rc;
     rc = sync_other_lanes(h);
     if (rc) return rc;
@@ -1498,8 +1498,14 @@ int rvll_slice_walk(rvll_handle* h, double* cube, double* theta, double* logl, i
     spec = std::max(1, std::min(spec, rvll::kMaxPointsPerBlock));
     rvll::WalkArgs w{h->d_walk_u, h->d_walk_theta, h->d_walk_logl, h->d_walk_chol, h->d_walk_wrapped, (long long)K,
                      nsteps, max_rounds, (unsigned long long)seed, lstar, h->d_walk_ncalls,
-                     h->d_walk_steps, nullptr, nullptr, (long long)walker_base, spec, h->d_walk_ncalls + 1};
-    HIP_TRY(rvll::launch_slice_walk(a, w, !slim, st));
+                     h->d_walk_steps, nullptr, nullptr, (long long)walker_base, spec, h->d_walk_ncalls + 1,
+                     h->d_walk_ncalls + kWalkWords - 1};
+    // no more workgroups than the chip holds at once; freed walker slots draw the remaining rows from a queue
+    // (RVLL_WALK_QUEUE, a measurement / test switch: 0 = one workgroup per PB rows, as many residency rounds as that
+    // takes; n > 0 = as many workgroups as n compute units hold, so that a small walk goes through the queue too)
+    const char* qenv = getenv("RVLL_WALK_QUEUE");
+    const int max_cus = qenv ? std::max(0, std::min(atoi(qenv), h->n_cu)) : h->n_cu;
+    HIP_TRY(rvll::launch_slice_walk(a, w, !slim, max_cus, st));
     unsigned long long n = 0, evaluated[kWalkWords] = {};
     h->walk_evaluated = 0;
     std::vector<int32_t> steps(slim ? (size_t)K : 0);
@@ -1532,7 +1538,7 @@ int rvll_slice_walk(rvll_handle* h, double* cube, double* theta, double* logl, i
             HIP_TRY(hipMemcpyAsync(h->d_walk_logl, sl.data(), sizeof(double) * M, hipMemcpyHostToDevice, st));
             HIP_TRY(hipMemcpyAsync(h->d_walk_wid, ids.data(), sizeof(int32_t) * M, hipMemcpyHostToDevice, st));
             HIP_TRY(hipMemcpyAsync(h->d_walk_start, start.data(), sizeof(int32_t) * M, hipMemcpyHostToDevice, st));
-            HIP_TRY(hipMemsetAsync(h->d_walk_ncalls, 0, 2 * sizeof(unsigned long long), st));   // the diagnostic bins keep adding up
+            HIP_TRY(hipMemsetAsync(h->d_walk_ncalls, 0, kWalkWords * sizeof(unsigned long long), st));
             rvll::LoglikeArgs a2;
             rc = walk_args((long long)M, &a2);
             if (rc) return rc;
@@ -1540,7 +1546,7 @@ int rvll_slice_walk(rvll_handle* h, double* cube, double* theta, double* logl, i
             w2.K = (long long)M;
             w2.walker_id = h->d_walk_wid;
             w2.step_start = h->d_walk_start;
-            HIP_TRY(rvll::launch_slice_walk(a2, w2, true, st));
+            HIP_TRY(rvll::launch_slice_walk(a2, w2, true, max_cus, st));
             HIP_TRY(hipMemcpyAsync(su.data(), h->d_walk_u, sizeof(double) * D * M, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipMemcpyAsync(sth.data(), h->d_walk_theta, sizeof(double) * D * M, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipMemcpyAsync(sl.data(), h->d_walk_logl, sizeof(double) * M, hipMemcpyDeviceToHost, st));
@@ -1548,7 +1554,7 @@ int rvll_slice_walk(rvll_handle* h, double* cube, double* theta, double* logl, i
             HIP_TRY(hipStreamSynchronize(st));
             total += evaluated[0];
             h->walk_evaluated += (long long)evaluated[1];
-            for (int k = 0; k < 5; ++k) h->walk_phase[k] = evaluated[2 + k];
+            for (int k = 0; k < 5; ++k) h->walk_phase[k] += evaluated[2 + k];
             for (size_t j = 0; j < M; ++j) {
                 memcpy(cube + (size_t)ids[j] * D, &su[j * D], sizeof(double) * D);
                 memcpy(theta + (size_t)ids[j] * D, &sth[j * D], sizeof(double) * D);

@@ -100,13 +100,16 @@ struct WalkArgs {
     int spec_max;              // candidates evaluated AHEAD per walker and iteration when the workgroup's tile has free
                                // slots (1: none): candidate r+1 is the one the walker draws if candidate r is rejected
     unsigned long long* nslots;   // or null: += tile slots evaluated (>= ncalls: includes speculative ones that went unused)
+    unsigned long long* queue;    // zeroed before the launch: ticket counter of the rows no workgroup started with
 };
 constexpr int kWalkCholLds = 48;   // the walk stages a whitening factor of up to 48 x 48 (18 KB) in LDS
 size_t walk_lds_bytes(const LoglikeArgs& a);
 // a: fused (cube -> theta -> log-L) arguments whose cube / theta_out / logL / flags rows [0, K) are scratch
 // fat = false: slim prior stage (4 waves per SIMD; deferring walkers report steps_done < nsteps);
 // fat = true : full solvers inline (every walker finishes)
-hipError_t launch_slice_walk(const LoglikeArgs& a, const WalkArgs& w, bool fat, hipStream_t stream);
+// max_cus > 0: launch at most as many workgroups as max_cus compute units hold at once (the rest of the rows are drawn
+// from w.queue by slots whose walker has finished); 0: one workgroup per PB rows
+hipError_t launch_slice_walk(const LoglikeArgs& a, const WalkArgs& w, bool fat, int max_cus, hipStream_t stream);
 
 // ---- scalar-call server: a one-workgroup persistent kernel that answers single-point log-L requests through a
 // block of host-coherent pinned memory, so a scalar callback costs a PCIe round trip instead of a kernel launch

@@ -7,6 +7,7 @@
 // flag would put ~30 extra scalar moves into every Newton iteration, enough to saturate the CU's one scalar unit;
 // they keep the default.)
 #define RVLL_LOCAL_CONSTS 1      // the Newton loop's constants are loaded in front of it, not inside it (rvll_math.h)
+#include <algorithm>
 #include "rvll_tile.h"
 
 namespace rvll {
@@ -32,6 +33,13 @@ namespace {
 // then consumed in order — accept the first one above lstar, shrink past the others — so positions, log-L, counters
 // and ncalls are bit for bit those of the one-candidate-per-iteration walk, whatever the workgroup geometry; only
 // the iterations a slow walker needs drop (nslots counts what was evaluated, ncalls what was used).
+// WALKER QUEUE.  The launch has at most as many workgroups as the chip holds at once; a workgroup's PB walker slots
+// start with walkers blockIdx * PB .. and every slot whose walker has finished (or was deferred) sends that walker's
+// row home and takes the next one from a global ticket counter, so all slots stay busy until no walker is left —
+// with a static split (one workgroup per PB walkers, two residency rounds at 16384 walkers) 28 % of the kernel's
+// duration was its tail, workgroups waiting for their slowest walker while the rest of the chip had drained.  The
+// random-number counters name the WALKER (row index + walker_base), never the slot, so which slot walks which row
+// changes nothing in the results.
 // FAT = false: the prior stage evaluates Beta / Gamma quantiles by their verified tables only (rvll_tile.h,
 // prior_heavy_slim).  A walker whose candidate needs anything else stops at the START of that move and reports the
 // number of completed moves in steps_done; the host finishes those walkers with the FAT instantiation (full solvers
@@ -68,8 +76,12 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
     int* acc_slot = nsp_of + PB;                            // [PB] per walker: the slot whose candidate was accepted
     int* used_of = acc_slot + PB;                           // [PB] per walker: candidates consumed this iteration
     int* slot_pl = used_of + PB;                            // [PB] per tile slot: its walker
-    int* nact_s  = slot_pl + PB;                            // [2]  active walkers, tile slots of this iteration
-    int* wrapped_s = nact_s + 2;                            // [D]  circular parameters
+    int* gid     = slot_pl + PB;                            // [PB] per walker slot: the row it is walking
+    int* gold    = gid + PB;                                // [PB] ... the row that has just finished there (to be sent home)
+    int* refill  = gold + PB;                               // [PB] 0 / 1: send gold home and load gid / 2: send gold home, slot stays empty
+    int* acc_g   = refill + PB;                             // [PB] row of the walker whose candidate was accepted (= gid then)
+    int* nact_s  = acc_g + PB;                              // [3]  active walkers, tile slots, slots to refill of this iteration
+    int* wrapped_s = nact_s + 3;                            // [D]  circular parameters
     const double* chol = chol_in_lds ? chol_s : w.chol;
     const TileLds L = tile_views(a, smem);                  // the tile's results are read back from LDS (tile_point_result)
     const double one_below = 0.99999999999999988898;        // nextafter(1, 0)
@@ -78,12 +90,13 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
     if (chol_in_lds) for (int i = tid; i < D * D; i += kThreads) chol_s[i] = w.chol[i];
     for (int i = tid; i < D; i += kThreads) wrapped_s[i] = w.wrapped[i];
     for (int i = tid; i < nw; i += kThreads) {
-        wl[i] = w.logl[w0 + i]; state[i] = 0; round_of[i] = 0;
+        wl[i] = w.logl[w0 + i]; state[i] = 0; round_of[i] = 0; refill[i] = 0; gid[i] = (int)(w0 + i);
         step_of[i] = w.step_start ? w.step_start[w0 + i] : 0;
     }
     __syncthreads();
-    // tile slots of the next iteration (thread 0): every active walker one, the free ones dealt out evenly, at most
-    // spec_max per walker and never past the move's last round
+    // ---- the bookkeeping thread's helpers ----
+    // tile slots of the next iteration: every active walker one, the free ones dealt out evenly, at most spec_max per
+    // walker and never past the move's last round
     auto deal_slots = [&](const int* act, int n) {
         const int base = n ? nw / n : 0, rem = n ? nw % n : 0;
         int f = 0;
@@ -95,13 +108,41 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
         }
         nact_s[0] = n; nact_s[1] = f;
     };
-    if (tid == kThreads - 1) {                              // walkers that still have moves to make (the bookkeeping thread)
-        int n = 0;
-        for (int i = 0; i < nw; ++i) if (step_of[i] < w.nsteps) act[n++] = i;
-        deal_slots(act, n);
-    }
+    // the next row nobody walks yet (rows with nothing left to do are ticked off on the way), or -1
+    const long long qbase = (long long)gridDim.x * PB;
+    bool queue_empty = false;
+    auto next_row = [&]() -> int {
+        while (!queue_empty) {
+            const long long q = qbase + (long long)atomicAdd(w.queue, 1ull);
+            if (q >= w.K) { queue_empty = true; break; }
+            const int ss = w.step_start ? w.step_start[q] : 0;
+            if (ss < w.nsteps) return (int)q;
+            if (w.steps_done) w.steps_done[q] = ss;
+        }
+        return -1;
+    };
+    // slot pl's walker is done (all moves made, or deferred): its row goes home at the top of the next iteration, where
+    // the slot also loads the row it takes over; returns whether the slot stays in the list
+    auto retire = [&](int pl) -> bool {
+        gold[pl] = gid[pl];
+        const int q = next_row();
+        refill[pl] = q >= 0 ? 1 : 2;
+        if (q < 0) return false;
+        gid[pl] = q; state[pl] = 0; round_of[pl] = 0;
+        return true;
+    };
     int* const act0 = act;
     unsigned long long calls = 0, slots = 0;                // the bookkeeping thread only
+    if (tid == kThreads - 1) {                              // walkers that still have moves to make
+        int n = 0, nref = 0;
+        for (int i = 0; i < nw; ++i) {
+            if (step_of[i] < w.nsteps) { act[n++] = i; continue; }
+            ++nref;
+            if (retire(i)) act[n++] = i;
+        }
+        deal_slots(act, n);
+        nact_s[2] = nref;
+    }
     __syncthreads();
 
     // phase clock of a diagnostic build (make walktrace; scripts/walk_phase_probe.py): thread 0 sums the time between
@@ -112,9 +153,26 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
 #else
 #define WALK_STAMP(k) do { } while (0)
 #endif
-    const long long max_iters = (long long)w.nsteps * w.max_rounds;
+    // every iteration consumes at least one candidate of every listed walker, so a slot's walkers end after at most
+    // nsteps * max_rounds iterations each; the bound below is the formal exit for the case that all rows pass one slot
+    const long long max_iters = ((long long)w.nsteps * w.max_rounds + 1) * (w.K + 1);
     for (long long iter = 0; iter < max_iters; ++iter) {
-        const int nact = nact_s[0], nslots = nact_s[1];
+        const int nact = nact_s[0], nslots = nact_s[1], nref = nact_s[2];
+        if (nref) {                                         // finished rows go home, the rows taking their slots come in
+            for (int i = tid; i < nw * D; i += kThreads) {
+                const int pl = i / D, k = i - pl * D, r = refill[pl];
+                if (!r) continue;
+                const long long go = gold[pl];
+                w.u[go * D + k] = wu[i];
+                if (k == 0) { w.logl[go] = wl[pl]; if (w.steps_done) w.steps_done[go] = step_of[pl]; }
+                if (r == 1) {
+                    const long long gn = gid[pl];
+                    wu[i] = w.u[gn * D + k];
+                    if (k == 0) { wl[pl] = w.logl[gn]; step_of[pl] = w.step_start ? w.step_start[gn] : 0; }
+                }
+            }
+            __syncthreads();
+        }
         if (nact == 0) break;
         act = act0 + (iter & 1) * PB;
         int* const act_next = act0 + ((iter + 1) & 1) * PB;
@@ -122,7 +180,7 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
         for (int i = tid; i < nact * D; i += kThreads) {
             const int pl = act[i / D], k = i % D;
             if (state[pl] != 0) continue;
-            const unsigned long long wid = (unsigned long long)(w.walker_base + (w.walker_id ? (long long)w.walker_id[w0 + pl] : w0 + pl));
+            const unsigned long long wid = (unsigned long long)(w.walker_base + (w.walker_id ? (long long)w.walker_id[gid[pl]] : (long long)gid[pl]));
             const unsigned long long ctr = (wid << 32) | ((unsigned long long)step_of[pl] << 14) | (unsigned)(2 * k);
             const double u1 = uniform01(w.seed, ctr), u2 = uniform01(w.seed, ctr + 1);
             double sn, cs;
@@ -173,7 +231,7 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
                 state[pl] = 1;
             }
             // this round's candidate and, in the walker's further slots, the ones the next rounds draw if it is rejected
-            const unsigned long long wid = (unsigned long long)(w.walker_base + (w.walker_id ? (long long)w.walker_id[w0 + pl] : w0 + pl));
+            const unsigned long long wid = (unsigned long long)(w.walker_base + (w.walker_id ? (long long)w.walker_id[gid[pl]] : (long long)gid[pl]));
             const unsigned long long ctr = (wid << 32) | ((unsigned long long)step_of[pl] << 14) | (unsigned)(8192 + round_of[pl]);
             double lo = tmin[pl], hi = tmax[pl];
             const int first = first_of[pl], S = nsp_of[pl];
@@ -211,7 +269,7 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
                 const double cl = tile_point_result(a, L, first + j, fl);
                 used = j + 1;
                 if (!FAT && (fl & kFlagDeferred)) { state[pl] = 3; break; }                        // leave at the start of this move
-                if (cl > w.lstar) { state[pl] = 2; wl[pl] = cl; acc_slot[pl] = first + j; break; }
+                if (cl > w.lstar) { state[pl] = 2; wl[pl] = cl; acc_slot[pl] = first + j; acc_g[pl] = gid[pl]; break; }
                 const double t = slot_t[first + j];
                 if (t < 0.) tmin[pl] = t; else tmax[pl] = t;
                 if (++round_of[pl] >= w.max_rounds) { state[pl] = 0; step_of[pl] += 1; break; }     // give the move up, stay put
@@ -226,24 +284,33 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
             const int sl = acc_slot[pl];
             if (sl < 0) continue;
             wu[pl * D + k] = cand[sl * D + k];
-            w.theta[(w0 + pl) * D + k] = L.theta_s[sl * D + k];
+            w.theta[(long long)acc_g[pl] * D + k] = L.theta_s[sl * D + k];
         }
         if (tid == kThreads - 1) {
             slots += (unsigned long long)nslots;
-            int n = 0;
+            int n = 0, nr = 0;
+            for (int i = 0; i < nw; ++i) refill[i] = 0;                 // last iteration's marks were served at the top
             for (int ai = 0; ai < nact; ++ai) {
                 const int pl = act[ai];
                 calls += (unsigned long long)used_of[pl];
                 if (state[pl] == 2) { state[pl] = 0; step_of[pl] += 1; }
-                if (step_of[pl] < w.nsteps && state[pl] != 3) act_next[n++] = pl;
+                if (step_of[pl] < w.nsteps && state[pl] != 3) { act_next[n++] = pl; continue; }
+                ++nr;
+                if (retire(pl)) act_next[n++] = pl;
             }
             deal_slots(act_next, n);
+            nact_s[2] = nr;
         }
         __syncthreads();
         WALK_STAMP(3);
     }
-    for (int i = tid; i < nw * D; i += kThreads) w.u[w0 * D + i] = wu[i];
-    for (int i = tid; i < nw; i += kThreads) { w.logl[w0 + i] = wl[i]; if (w.steps_done) w.steps_done[w0 + i] = step_of[i]; }
+    // (only if the formal bound above ended the loop: rows still being walked go home as they are)
+    for (int i = tid; i < nact_s[0] * D; i += kThreads) {
+        const int pl = (act0 + (max_iters & 1) * PB)[i / D], k = i % D;
+        const long long g = gid[pl];
+        w.u[g * D + k] = wu[pl * D + k];
+        if (k == 0) { w.logl[g] = wl[pl]; if (w.steps_done) w.steps_done[g] = step_of[pl]; }
+    }
     if (tid == kThreads - 1 && calls) atomicAdd(w.ncalls, calls);
     if (tid == kThreads - 1 && slots && w.nslots) atomicAdd(w.nslots, slots);
 #ifdef RVLL_WALK_TRACE
@@ -261,27 +328,40 @@ size_t walk_lds_bytes(const LoglikeArgs& a)
 {
     const size_t base = (loglike_lds_bytes(a) + 15) & ~(size_t)15;
     return base + sizeof(double) * ((size_t)5 * a.PB * a.D + 4 * a.PB + (a.D <= kWalkCholLds ? a.D * a.D : 0)) +
-           sizeof(int) * (10 * a.PB + 2 + a.D) + 16;
+           sizeof(int) * (14 * a.PB + 3 + a.D) + 16;
 }
 
-hipError_t launch_slice_walk(const LoglikeArgs& a, const WalkArgs& w, bool fat, hipStream_t stream)
+hipError_t launch_slice_walk(const LoglikeArgs& a, const WalkArgs& w, bool fat, int max_cus, hipStream_t stream)
 {
     if (w.K <= 0 || w.nsteps <= 0) return hipSuccess;
     if (!a.cube || !a.theta_out || !a.priors || !a.flags || a.PB * a.D > 4 * kThreads || w.nsteps >= (1 << 18) ||
         w.max_rounds < 1 || w.max_rounds > 4096 || a.D > 4096 || (!fat && !w.steps_done) || w.spec_max < 1)
         return hipErrorInvalidValue;
     const size_t lds = walk_lds_bytes(a);
-    if (lds > 64 * 1024) return hipErrorInvalidValue;
-    const dim3 grid((unsigned)((w.K + a.PB - 1) / a.PB)), block(kThreads);
+    if (lds > 64 * 1024 || !w.queue) return hipErrorInvalidValue;
+    // max_cus > 0: no more workgroups than the chip holds at once; their slots draw the remaining rows from the queue
+    long long nblocks = (w.K + a.PB - 1) / a.PB;
+    const dim3 block(kThreads);
+#define RVLL_WALK_ONE(KERNEL)                                                                                        \
+    do {                                                                                                             \
+        if (max_cus > 0) {                                                                                           \
+            int occ = 0;                                                                                             \
+            const hipError_t e_ = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, KERNEL, kThreads, lds);        \
+            if (e_ != hipSuccess) return e_;                                                                         \
+            nblocks = std::min(nblocks, (long long)std::max(1, occ) * max_cus);                                     \
+        }                                                                                                            \
+        hipLaunchKernelGGL(KERNEL, dim3((unsigned)nblocks), block, lds, stream, a, w);                               \
+    } while (0)
 #define RVLL_WALK(PREC)                                                                                              \
-    if (fat) hipLaunchKernelGGL((slice_walk_kernel<PREC, true>), grid, block, lds, stream, a, w);                    \
-    else     hipLaunchKernelGGL((slice_walk_kernel<PREC, false>), grid, block, lds, stream, a, w)
+    if (fat) RVLL_WALK_ONE((slice_walk_kernel<PREC, true>));                                                        \
+    else     RVLL_WALK_ONE((slice_walk_kernel<PREC, false>))
     switch (a.precision) {
     case RVLL_PREC_MIXED: RVLL_WALK(RVLL_PREC_MIXED); break;
     case RVLL_PREC_FP32:  RVLL_WALK(RVLL_PREC_FP32); break;
     default:              RVLL_WALK(RVLL_PREC_FP64); break;
     }
 #undef RVLL_WALK
+#undef RVLL_WALK_ONE
     return hipGetLastError();
 }
 

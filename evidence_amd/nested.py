@@ -199,15 +199,16 @@ def run_nested_slice(prior: Callable, loglike: Callable, ndim: int, nlive: Optio
         a_last = np.exp(big - logz_seq[-1]) * (a_prev + float(np.sum(np.exp(logw - big) * dl)))
         logz, logx = float(logz_seq[-1]), float(logx_seq[-1])
         h = float(a_last - logz)
-        dead_theta.append(theta[dead].copy()); dead_logl.append(dl.copy()); dead_logw.append(logw)
+        dead_theta.append(theta[dead]); dead_logl.append(dl); dead_logw.append(logw)      # (index arrays: already copies)
         it += kbatch
         alive = order[kbatch:]
         # whitening from the surviving live points
-        d0 = u[alive] - u[alive].mean(axis=0)
+        ua = u[alive]
+        d0 = ua - ua.mean(axis=0)
         cov = d0.T @ d0 / max(1, len(alive) - 1) + 1e-14 * np.eye(ndim)
         chol = np.linalg.cholesky(cov)
         start = alive[rng.integers(0, len(alive), kbatch)]
-        wu, wt, wl = u[start].copy(), theta[start].copy(), logl[start].copy()
+        wu, wt, wl = u[start], theta[start], logl[start]
         if walker is not None:
             wu, wt, wl, used = walker(wu, wt, wl, lstar, chol, wrapped, nsteps, 200, int(rng.integers(0, 2 ** 62)))
             ncall += int(used)

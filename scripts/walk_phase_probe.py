@@ -17,11 +17,14 @@ ap.add_argument("--walkers", type=int, default=16384)
 ap.add_argument("--nsteps", type=int, default=57)
 ap.add_argument("--quantile", type=float, default=0.5)
 ap.add_argument("--ahead", type=int, default=0, help="rvll_set_walk_speculation (0: library default)")
+ap.add_argument("--pb", type=int, default=0, help="walkers per workgroup (0: library default)")
 args = ap.parse_args()
 w = make_workload(3)
 with GpuRVModel(w.fixedpardict, w.table, w.parnames, priordict=w.priordict()) as m:
     if args.ahead:
         m.set_walk_speculation(args.ahead)
+    if args.pb:
+        m.set_points_per_block(args.pb)
     rng = np.random.default_rng(0)
     K = args.walkers
     cube = rng.random((int(K / (1 - args.quantile)) + 64, m.ndim))

@@ -189,3 +189,58 @@ def test_sharded_walk_draws_what_the_unsharded_walk_draws(gpu_required):
             assert sum(p[3] for p in parts) == full[3]
         other = m.slice_walk(cube[:100], theta[:100], logl[:100], lstar, chol, wr, nsteps=7, seed=6, walker_base=100)
     assert not np.array_equal(other[0], full[0][:100])            # other rows, other draws
+
+
+def test_speculation_and_the_walker_queue_change_nothing_in_the_results(gpu_required, monkeypatch):
+    """Two things about HOW the walk is scheduled must not show in WHAT it returns: free tile slots evaluating a
+    walker's next candidates ahead (rvll_set_walk_speculation; consumed in the order the walker would have met them),
+    and freed walker slots drawing the remaining rows from a queue (the launch holds no more workgroups than the chip
+    does).  End points, log-L and the number of likelihood calls are those of one candidate per walker and iteration
+    with one workgroup per PB rows — also when walkers are deferred to the full-solver instantiation on the way."""
+    w = make_workload(3)
+    with GpuRVModel(w.fixedpardict, w.table, w.parnames, priordict=w.priordict()) as m:
+        cube, theta, logl, lstar, chol = _start(m, w, 2600, seed=41, quantile=0.8)
+        wr = wrapped_params(m.parnames)
+        m.set_points_per_block(8)                                  # (a walk this small would get one walker per workgroup)
+        runs = {}
+        for umax in (30.0, 1.0):                                   # nobody deferred / about half of the candidates
+            m.set_slim_table_range(umax)
+            for queue in ("0", "1", "3", None):                    # off / 1 CU's worth of workgroups / 3 / the whole chip
+                if queue is None:
+                    monkeypatch.delenv("RVLL_WALK_QUEUE", raising=False)
+                else:
+                    monkeypatch.setenv("RVLL_WALK_QUEUE", queue)
+                for ahead in (1, 2, 4, 8):
+                    m.set_walk_speculation(ahead)
+                    out = m.slice_walk(cube, theta, logl, lstar, chol, wr, nsteps=9, seed=5)
+                    runs[(umax, queue, ahead)] = out + (m.slice_walk_evaluated(),)
+    for umax in (30.0, 1.0):
+        ref = runs[(umax, "0", 1)]
+        assert ref[4] == ref[3]                                    # no speculation: every evaluated slot is a call
+        for key, got in runs.items():
+            if key[0] != umax:
+                continue
+            assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]), key
+            assert got[3] == ref[3], key
+            assert got[4] >= got[3] and (key[2] > 1 or got[4] == got[3]), key
+    assert runs[(30.0, "1", 4)][4] > runs[(30.0, "1", 4)][3]       # speculation did evaluate candidates ahead
+    assert np.array_equal(runs[(30.0, "0", 1)][0], runs[(1.0, "0", 1)][0])      # and deferral changes nothing either
+
+
+def test_queue_serves_rows_with_nothing_left_to_do_and_a_ragged_last_workgroup(gpu_required, monkeypatch):
+    """Sizes around the queue's edges: fewer walkers than one workgroup holds, a walker count that is not a multiple of
+    the group size, one workgroup serving every row."""
+    w = make_workload(1)
+    with GpuRVModel(w.fixedpardict, w.table, w.parnames, priordict=w.priordict()) as m:
+        wr = wrapped_params(m.parnames)
+        for k in (7, 37, 530):
+            cube, theta, logl, lstar, chol = _start(m, w, k, seed=50 + k)
+            monkeypatch.setenv("RVLL_WALK_QUEUE", "0")
+            ref = m.slice_walk(cube, theta, logl, lstar, chol, wr, nsteps=5, seed=9)
+            for pb in (1, 5, 0):
+                m.set_points_per_block(pb)
+                monkeypatch.setenv("RVLL_WALK_QUEUE", "1")
+                got = m.slice_walk(cube, theta, logl, lstar, chol, wr, nsteps=5, seed=9)
+                assert all(np.array_equal(a, b) for a, b in zip(got[:3], ref[:3])) and got[3] == ref[3], (k, pb)
+            th_chk, ll_chk = m.prior_loglike_batch(ref[0])
+            assert np.array_equal(th_chk, ref[1]) and np.array_equal(ll_chk, ref[2])
