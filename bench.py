@@ -334,19 +334,45 @@ def run_extras(out, model, w, theta, B, with_cpu):
                 model.log_likelihood(x0)
             lat[mode] = (time.perf_counter() - t1) / 1000 * 1e6
         out["scalar_call_us"] = {"launch_per_call": lat["launch"], "persistent_kernel": lat["server"]}
+        # PolyChord's sequence per point: prior(cube), then loglike(of the theta it returned)
+        from evidence_amd.callbacks import make_polychord_callbacks
+        model.set_priors(w.priordict())
+        cubes = w.sample_cube(256, seed=3)
+        for name, kw in (("two_requests", {}), ("one_request", {"low_latency": True})):
+            model.scalar_server(True)
+            prior, loglike, _, _ = make_polychord_callbacks(model, **kw)
+            for c in cubes[:32]:
+                loglike(prior(c))
+            t1 = time.perf_counter()
+            for c in cubes:
+                loglike(prior(c))
+            out["scalar_call_us"]["polychord_pair_" + name] = (time.perf_counter() - t1) / len(cubes) * 1e6
+        model.scalar_server(False)
 
     def nested_sampling():                # end to end with the proposal walk on the device
         from evidence_amd.callbacks import make_ultranest_callbacks, wrapped_params
         from evidence_amd.nested import run_nested_slice
         model.set_priors(w.priordict())
         vprior, vloglike = make_ultranest_callbacks(model, vectorized=True)
+        inside = {"s": 0.0, "calls": 0, "slots": 0}
+
+        def walker(*a):                   # the walk call by itself, and what it evaluated beyond the calls it reports
+            t2 = time.perf_counter()
+            res = model.slice_walk(*a)
+            inside["s"] += time.perf_counter() - t2
+            inside["calls"] += res[3]
+            inside["slots"] += model.slice_walk_evaluated()
+            return res
+
         t1 = time.perf_counter()
         ns = run_nested_slice(vprior, vloglike, model.ndim, nlive=32768, kbatch=16384, dlogz=1e-9,
                               max_calls=60_000_000, wrapped=wrapped_params(model.parnames), seed=1,
-                              prior_loglike=model.prior_loglike_batch, walker=model.slice_walk)
+                              prior_loglike=model.prior_loglike_batch, walker=walker)
         out["nested_sampling_end_to_end"] = {"likelihood_calls_per_s": ns.ncall / (time.perf_counter() - t1),
                                              "calls": int(ns.ncall), "live_points": 32768, "deaths_per_iteration": 16384,
-                                             "walk": "device (rvll_slice_walk)"}
+                                             "walk": "device (rvll_slice_walk)",
+                                             "inside_walk_calls_per_s": inside["calls"] / inside["s"],
+                                             "tile_slots_evaluated_per_call": inside["slots"] / max(1, inside["calls"])}
 
     def fip():
         out["fip_periodogram"] = fip_extra(with_cpu)

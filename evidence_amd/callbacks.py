@@ -29,16 +29,29 @@ def make_polychord_callbacks(model, low_latency: bool = False) -> Tuple[Callable
 
     PolyChord calls prior(cube) and loglike(theta) one point at a time.  low_latency=True answers both through
     the model's persistent scalar-call kernel (GpuRVModel.scalar_server): ~19 us per prior + loglike pair at
-    cfg3 instead of ~45 us with a launch and a synchronisation per call; same bits."""
+    cfg3 instead of ~45 us with a launch and a synchronisation per call; same bits.  PolyChord's loglike(theta) always
+    follows prior(cube) with the theta that call returned (evidence/polychord/__init__.py:130-171 hands it both
+    closures): in the low-latency form prior() therefore asks for the pair in one request and loglike() answers from
+    that when it is handed exactly that theta (compared element by element; anything else is evaluated as usual)."""
     ndim, nderived = len(model.parnames), 0
     if low_latency:
         model.scalar_server(True)
+    last = {"theta": None, "logl": 0.0}
 
     def prior(hypercube):
         cube = np.asarray(hypercube, dtype=np.float64)
-        return model.prior_transform(cube)
+        if not low_latency:
+            return model.prior_transform(cube)
+        theta, logl = model.prior_loglike(cube)
+        last["theta"], last["logl"] = theta.copy(), logl
+        return theta
 
     def loglike(x):
+        t = last["theta"]
+        if t is not None:
+            xa = np.asarray(x, dtype=np.float64)
+            if xa.shape == t.shape and np.array_equal(xa, t):
+                return (last["logl"], [])
         return (model.log_likelihood(x), [])
 
     return prior, loglike, ndim, nderived

@@ -1211,6 +1211,7 @@ int scalar_call(rvll_handle* h, unsigned op, const double* theta, double* logL, 
         memcpy(theta_out, c->theta, sizeof(double) * (size_t)h->L.ndim);
         return RVLL_OK;
     }
+    if (op == rvll::kServerPriorLogLike && theta_out) memcpy(theta_out, c->theta, sizeof(double) * (size_t)h->L.ndim);
     if (logL) *logL = c->answer.logL;          // same 16-byte store as the number just seen
     if (flags) *flags = c->answer.flags;
     return RVLL_OK;
@@ -1321,6 +1322,8 @@ int rvll_prior_loglike_batch(rvll_handle* h, const double* cube, int64_t B,
     if (h && !h->have_priors) return fail(RVLL_E_NOPRIORS, "rvll_set_priors has not been called");
     if (B == 0) return use_device(h);
     if (!cube || !logL) return fail(RVLL_E_INVALID, "cube/logL is null");
+    if (B == 1 && h->srv_enabled)             // the scalar pair prior(cube) + loglike(theta) as ONE request of the server
+        return scalar_call(h, rvll::kServerPriorLogLike, cube, logL, flags, theta_out);
     const size_t nin = sizeof(double) * (size_t)B * (size_t)h->L.ndim;
     const size_t nout = (sizeof(double) + sizeof(int32_t)) * (size_t)B;
     if (nin <= 64 * 1024 && nout <= 64 * 1024 && h->all_direct) {

@@ -116,7 +116,8 @@ hipError_t launch_slice_walk(const LoglikeArgs& a, const WalkArgs& w, bool fat, 
 // and a stream synchronisation.  Host and device share this layout; every field sits on its own cache line.
 constexpr int kServerMaxDim = 448;
 constexpr unsigned kServerRunning = 1u, kServerExited = 2u;
-constexpr unsigned kServerLogLike = 0u, kServerPrior = 1u, kServerNoop = 2u, kServerQuit = 3u;
+constexpr unsigned kServerLogLike = 0u, kServerPrior = 1u, kServerNoop = 2u, kServerQuit = 3u,
+                   kServerPriorLogLike = 4u;   // prior(cube) and log-L of the result in one request (PolyChord's pair)
 struct ServerAnswer { double logL; unsigned int number; int flags; };      // 16 bytes: leaves the GPU as ONE store
 struct ServerCtl {
     alignas(64) unsigned long long request;   // host -> device, one 64-bit store: (op << 32) | request number;

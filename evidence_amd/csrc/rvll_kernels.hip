@@ -91,17 +91,30 @@ void scalar_server_kernel(const LoglikeArgs a, ServerCtl* ctl, unsigned long lon
         if (word[1] != 0) break;
         const unsigned op = (unsigned)(r >> 32);
         ServerAnswer ans{0., (unsigned)r, 0};
-        if (op == kServerPrior) {
+        if (op == kServerPrior || op == kServerPriorLogLike) {
             // prior(cube): the row is transformed in place (staged through LDS first: the sorted kinds read
             // the whole row).  a.priors is null until rvll_set_priors; the host does not send the op before.
+            // kServerPriorLogLike: the sampler's next call is loglike(of exactly this theta) — evaluate it now, from
+            // the LDS copy of theta rather than back over PCIe, and send both with one answer.
             double* row = smem;
+            double* trow = reinterpret_cast<double*>(word + 2);
             for (int d = threadIdx.x; d < a.D; d += kThreads) row[d] = ctl->theta[d];
             __syncthreads();
-            for (int d = threadIdx.x; d < a.D; d += kThreads)
-                ctl->theta[d] = prior_is_heavy(a.priors[d].kind) ? prior_heavy(a.priors[d], row[d])
-                                                                 : prior_light(a.priors, a.D, row, d);
+            for (int d = threadIdx.x; d < a.D; d += kThreads) {
+                const double v = prior_is_heavy(a.priors[d].kind) ? prior_heavy(a.priors[d], row[d])
+                                                                  : prior_light(a.priors, a.D, row, d);
+                ctl->theta[d] = v;
+                trow[d] = v;
+            }
             __threadfence_system();                   // every thread's theta stores are out before the answer
             __syncthreads();
+            if (op == kServerPriorLogLike) {
+                loglike_tile<PREC, kFusedNone>(a, smem, 0, 1, trow);
+                if (threadIdx.x == 0) {
+                    ans.logL = __hip_atomic_load(a.logL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ans.flags = __hip_atomic_load(a.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
         } else if (op == kServerLogLike) {
             loglike_tile<PREC, kFusedNone>(a, smem, 0, 1);
             if (threadIdx.x == 0) {                   // thread 0 wrote a.logL[0] / a.flags[0] itself
@@ -386,7 +399,7 @@ hipError_t launch_scalar_server(const LoglikeArgs& a, ServerCtl* ctl, unsigned l
                                 unsigned long long idle_ticks, hipStream_t stream)
 {
     if (a.B != 1 || a.PB != 1 || !ctl || a.D > kServerMaxDim) return hipErrorInvalidValue;
-    const size_t lds = loglike_lds_bytes(a) + 2 * sizeof(unsigned long long);
+    const size_t lds = loglike_lds_bytes(a) + 2 * sizeof(unsigned long long) + sizeof(double) * (size_t)a.D;   // + request words, theta copy
     const dim3 grid(1), block(kThreads);
     switch (a.precision) {
     case RVLL_PREC_MIXED: hipLaunchKernelGGL((scalar_server_kernel<RVLL_PREC_MIXED>), grid, block, lds, stream, a, ctl, last, idle_ticks); break;

@@ -440,7 +440,7 @@ __device__ __forceinline__ void tile_stage(const LoglikeArgs& __restrict__ a, co
             dst[pl * a.D + d] = v;
         }
     } else {
-        const double* src = a.theta + p0 * a.D;
+        const double* src = cube_rows ? cube_rows : a.theta + p0 * a.D;       // (the theta form's rows, likewise)
         for (int i = tid; i < npts * a.D; i += NT) L.theta_s[i] = src[i];
         if (stamp && tid == 0) {                    // diagnostic builds: theta has landed in this wave
             __builtin_amdgcn_s_waitcnt(0);

@@ -189,6 +189,18 @@ class GpuRVModel:
             _abi.check(rc)
         return self._s_th[0, :self.ndim].copy().reshape(cube.shape)
 
+    def prior_loglike(self, cube):
+        """Scalar pair: prior(cube) and the log-L of the result in ONE call — (theta, logL).  With the scalar server on,
+        one request of the persistent kernel instead of two (what PolyChord's prior + loglike sequence amounts to)."""
+        cube = np.asarray(cube, dtype=np.float64)
+        if cube.size != self.ndim:
+            raise ValueError(f"expected {self.ndim} coordinates, got {cube.size}")
+        self._s_in[0, :self.ndim] = cube.ravel()
+        rc = self._lib.rvll_prior_loglike_batch(self._h, self._s_in_p, 1, self._s_th_p, self._s_out_p, self._s_flag_p)
+        if rc:
+            _abi.check(rc)
+        return self._s_th[0, :self.ndim].copy().reshape(cube.shape), float(self._s_out[0])
+
     def prior_loglike_batch(self, cubes, return_flags=False):
         """Fused prior(cube) -> theta -> log-L: one upload, two launches, one download."""
         cubes = self._theta2d(cubes)

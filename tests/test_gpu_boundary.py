@@ -345,6 +345,18 @@ def test_scalar_server_answers_polychord_style_calls(gpu_required):
             th = prior(c)
             assert np.array_equal(th, th_w)
             assert loglike(th)[0] == ll_w
+        # the low-latency closures ask for prior + log-L in ONE request and answer loglike(theta) from it — only when
+        # handed exactly the theta prior() returned; same bits as the two separate calls, with or without the server
+        prior2, loglike2, _, _ = make_polychord_callbacks(m, low_latency=True)
+        for c, th_w, ll_w in zip(cubes, th_want, ll_want):
+            th = prior2(c)
+            assert np.array_equal(th, th_w)
+            assert loglike2(th)[0] == ll_w                          # from the pair
+            assert loglike2(th_want[0])[0] == ll_want[0]            # any other theta: evaluated as usual
+        th1, ll1 = m.prior_loglike(cubes[3])
+        m.scalar_server(False)
+        th2, ll2 = m.prior_loglike(cubes[3])
+        assert np.array_equal(th1, th_want[3]) and np.array_equal(th2, th_want[3]) and ll1 == ll_want[3] and ll2 == ll_want[3]
     # both handles were destroyed with their servers possibly still polling: a new model works at once
     with GpuRVModel(case.fixed, case.table, case.parnames) as m3:
         assert np.array_equal(m3.log_likelihood_batch(case.theta[:10]), want[:10])
