@@ -146,6 +146,16 @@ def _chord(u, d, wrapped):
     return lo.max(axis=1), hi.min(axis=1)
 
 
+def _stable_argsort(x):
+    """np.argsort(x, kind="stable"), by way of the (vectorised, ~8x faster) unstable sort whenever that is provably
+    the same permutation: no two equal neighbours in the sorted order means no ties to break."""
+    order = np.argsort(x)
+    xs = x[order]
+    if np.any(xs[1:] == xs[:-1]) or np.isnan(xs[-1] if xs.size else 0.0):
+        return np.argsort(x, kind="stable")
+    return order
+
+
 def run_nested_slice(prior: Callable, loglike: Callable, ndim: int, nlive: Optional[int] = None, kbatch: Optional[int] = None,
                      nsteps: Optional[int] = None, dlogz: float = 0.5, max_iter: int = 10_000_000,
                      max_calls: int = 50_000_000, wrapped=None, seed: int = 0,
@@ -183,7 +193,7 @@ def run_nested_slice(prior: Callable, loglike: Callable, ndim: int, nlive: Optio
     logz, h, logx = -np.inf, 0.0, 0.0
     it = 0
     while it < max_iter and ncall < max_calls:
-        order = np.argsort(logl, kind="stable")
+        order = _stable_argsort(logl)
         dead = order[:kbatch]
         lstar = logl[dead[-1]]
         # the kbatch deaths in order, live count nlive - i while they die — vectorised (this loop used to cost more
