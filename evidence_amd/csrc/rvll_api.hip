@@ -229,6 +229,7 @@ struct rvll_handle {
     int32_t* d_walk_wrapped = nullptr;
     unsigned long long* d_walk_ncalls = nullptr;
     int32_t *d_walk_steps = nullptr, *d_walk_wid = nullptr, *d_walk_start = nullptr;   // [walk_cap] each
+    int32_t *d_walk_cost = nullptr, *d_walk_order = nullptr;                            // [walk_cap] each (two-part walks)
     int walk_spec = 4;                          // candidates a walker may evaluate ahead per iteration (rvll_set_walk_speculation)
     long long walk_evaluated = 0;               // tile slots the last rvll_slice_walk evaluated (>= its ncalls)
     unsigned long long walk_phase[5] = {};      // diagnostic build (make walktrace): 100 MHz ticks per phase, summed over workgroups; workgroups
@@ -1449,6 +1450,7 @@ int rvll_slice_walk(rvll_handle* h, double* cube, double* theta, double* logl, i
         HIP_TRY(hipStreamSynchronize(h->compute));
         dev_free(h->d_walk_u); dev_free(h->d_walk_theta); dev_free(h->d_walk_logl);
         dev_free(h->d_walk_steps); dev_free(h->d_walk_wid); dev_free(h->d_walk_start);
+        dev_free(h->d_walk_cost); dev_free(h->d_walk_order);
         h->walk_cap = 0;
         const size_t cap = (size_t)std::max<long long>(K, 1024);
         HIP_TRY(hipMalloc(&h->d_walk_u, sizeof(double) * D * cap));
@@ -1457,6 +1459,8 @@ int rvll_slice_walk(rvll_handle* h, double* cube, double* theta, double* logl, i
         HIP_TRY(hipMalloc(&h->d_walk_steps, sizeof(int32_t) * cap));
         HIP_TRY(hipMalloc(&h->d_walk_wid, sizeof(int32_t) * cap));
         HIP_TRY(hipMalloc(&h->d_walk_start, sizeof(int32_t) * cap));
+        HIP_TRY(hipMalloc(&h->d_walk_cost, sizeof(int32_t) * cap));
+        HIP_TRY(hipMalloc(&h->d_walk_order, sizeof(int32_t) * cap));
         if (!h->d_walk_chol) {
             HIP_TRY(hipMalloc(&h->d_walk_chol, sizeof(double) * D * D));
             HIP_TRY(hipMalloc(&h->d_walk_wrapped, sizeof(int32_t) * D));
@@ -1502,13 +1506,79 @@ int rvll_slice_walk(rvll_handle* h, double* cube, double* theta, double* logl, i
     rvll::WalkArgs w{h->d_walk_u, h->d_walk_theta, h->d_walk_logl, h->d_walk_chol, h->d_walk_wrapped, (long long)K,
                      nsteps, max_rounds, (unsigned long long)seed, lstar, h->d_walk_ncalls,
                      h->d_walk_steps, nullptr, nullptr, (long long)walker_base, spec, h->d_walk_ncalls + 1,
-                     h->d_walk_ncalls + kWalkWords - 1};
+                     h->d_walk_ncalls + kWalkWords - 1, nullptr, nullptr};
     // no more workgroups than the chip holds at once; freed walker slots draw the remaining rows from a queue
     // (RVLL_WALK_QUEUE, a measurement / test switch: 0 = one workgroup per PB rows, as many residency rounds as that
     // takes; n > 0 = as many workgroups as n compute units hold, so that a small walk goes through the queue too)
     const char* qenv = getenv("RVLL_WALK_QUEUE");
     const int max_cus = qenv ? std::max(0, std::min(atoi(qenv), h->n_cu)) : h->n_cu;
+    // With more rows than walker slots the kernel ends in a drain: the rows handed out last still take a whole walk
+    // (phase clock: mean workgroup life 7.2 ms of a 9.5 ms kernel at 16384 rows).  What a row costs per move is a
+    // property of where it walks, so the walk is launched in two parts: the first quarter of the moves for every row,
+    // counting the candidates each one needs; then the rest, rows handed out most expensive first — the late ones are the
+    // short ones.  Results are those of one launch (the moves of a row do not care which launch makes them).
+    // RVLL_WALK_PARTS=1: one launch (measurement switch).
+    const long long resident = max_cus > 0 ? rvll::slice_walk_resident_blocks(a, !slim, max_cus) : 0;
+    const char* penv = getenv("RVLL_WALK_PARTS");
+    const bool two_parts = resident > 0 && K > resident * a.PB && nsteps >= 8 && !(penv && atoi(penv) == 1);
+    if (two_parts) {
+        w.nsteps = std::max(1, nsteps / 4);
+        if (const char* e = getenv("RVLL_WALK_FIRST")) w.nsteps = std::max(1, std::min(nsteps - 1, atoi(e)));   // measurement switch
+        w.cost = h->d_walk_cost;
+    }
     HIP_TRY(rvll::launch_slice_walk(a, w, !slim, max_cus, st));
+    if (two_parts) {
+        const int first = w.nsteps;
+        std::vector<int32_t> cost((size_t)K), done((size_t)K), order((size_t)K);
+        HIP_TRY(hipMemcpyAsync(cost.data(), h->d_walk_cost, sizeof(int32_t) * (size_t)K, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(done.data(), h->d_walk_steps, sizeof(int32_t) * (size_t)K, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        // counting sort, most expensive first; rows that did not complete the first part (deferred) go last
+        const int32_t cmax = std::min<int32_t>(first * max_rounds, 1 << 16);
+        std::vector<int32_t> count((size_t)cmax + 2, 0);
+        auto key = [&](int64_t i) { return done[(size_t)i] >= first ? std::min(std::max(cost[(size_t)i], 0), cmax) + 1 : 0; };
+        for (int64_t i = 0; i < K; ++i) ++count[(size_t)key(i)];
+        const int32_t nkey0 = count[0];                  // rows the first part deferred: left to the full-solver pass below
+        if (getenv("RVLL_WALK_COST_DUMP")) {
+            std::vector<int32_t> cs(cost);
+            std::sort(cs.begin(), cs.end());
+            double sum = 0; for (int32_t c : cs) sum += c;
+            fprintf(stderr, "[walk cost, first %d moves] K=%lld mean %.1f  p50 %d  p90 %d  p99 %d  p99.9 %d  max %d\n", first, (long long)K,
+                    sum / (double)K, cs[(size_t)(K / 2)], cs[(size_t)(K * 9 / 10)], cs[(size_t)(K * 99 / 100)], cs[(size_t)(K * 999 / 1000)], cs.back());
+        }
+        int32_t pos = 0;
+        for (int32_t c = cmax + 1; c >= 0; --c) { const int32_t n_c = count[(size_t)c]; count[(size_t)c] = pos; pos += n_c; }
+        for (int64_t i = 0; i < K; ++i) order[(size_t)count[(size_t)key(i)]++] = (int32_t)i;
+        const int64_t K2 = K - nkey0;
+        w.nsteps = nsteps;
+        w.cost = nullptr;
+        {
+            // the workgroups' first rows: deal the G * PB most expensive ones round the workgroups like cards, so that
+            // every workgroup starts with one of the G longest, one of the next G, ... — eight long rows in one
+            // workgroup would leave it no free tile slot to evaluate candidates ahead with, and they are the critical path
+            const int64_t G = std::min<int64_t>((K2 + a.PB - 1) / a.PB, resident), first_rows = std::min<int64_t>(G * a.PB, K2);
+            std::vector<int32_t> dealt((size_t)first_rows);
+            int64_t k = 0;
+            for (int64_t pl = 0; pl < a.PB; ++pl)
+                for (int64_t b = 0; b < G; ++b) {
+                    const int64_t slot = b * a.PB + pl;
+                    if (slot < first_rows && k < first_rows) dealt[(size_t)slot] = order[(size_t)k++];
+                }
+            std::copy(dealt.begin(), dealt.end(), order.begin());
+        }
+        if (K2 > 0) {
+            HIP_TRY(hipMemcpyAsync(h->d_walk_order, order.data(), sizeof(int32_t) * (size_t)K2, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemsetAsync(h->d_walk_ncalls + kWalkWords - 1, 0, sizeof(unsigned long long), st));   // the queue; the counts go on
+            w.K = K2;
+            w.order = h->d_walk_order;
+            w.step_start = h->d_walk_steps;    // every row resumes where the first part left it (read before it is rewritten)
+            HIP_TRY(rvll::launch_slice_walk(a, w, !slim, max_cus, st));
+            HIP_TRY(hipStreamSynchronize(st)); // `order` goes out of scope
+            w.K = K;
+            w.order = nullptr;
+            w.step_start = nullptr;
+        }
+    }
     unsigned long long n = 0, evaluated[kWalkWords] = {};
     h->walk_evaluated = 0;
     std::vector<int32_t> steps(slim ? (size_t)K : 0);

@@ -101,6 +101,8 @@ struct WalkArgs {
                                // slots (1: none): candidate r+1 is the one the walker draws if candidate r is rejected
     unsigned long long* nslots;   // or null: += tile slots evaluated (>= ncalls: includes speculative ones that went unused)
     unsigned long long* queue;    // zeroed before the launch: ticket counter of the rows no workgroup started with
+    const int32_t* order;         // [K] or null: the order in which rows are handed to walker slots (default: by index)
+    int32_t* cost;                // [K] or null, out: candidates every row used in this launch
 };
 constexpr int kWalkCholLds = 48;   // the walk stages a whitening factor of up to 48 x 48 (18 KB) in LDS
 size_t walk_lds_bytes(const LoglikeArgs& a);
@@ -110,6 +112,7 @@ size_t walk_lds_bytes(const LoglikeArgs& a);
 // max_cus > 0: launch at most as many workgroups as max_cus compute units hold at once (the rest of the rows are drawn
 // from w.queue by slots whose walker has finished); 0: one workgroup per PB rows
 hipError_t launch_slice_walk(const LoglikeArgs& a, const WalkArgs& w, bool fat, int max_cus, hipStream_t stream);
+long long slice_walk_resident_blocks(const LoglikeArgs& a, bool fat, int cus);
 
 // ---- scalar-call server: a one-workgroup persistent kernel that answers single-point log-L requests through a
 // block of host-coherent pinned memory, so a scalar callback costs a PCIe round trip instead of a kernel launch

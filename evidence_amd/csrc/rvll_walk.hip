@@ -39,7 +39,8 @@ namespace {
 // with a static split (one workgroup per PB walkers, two residency rounds at 16384 walkers) 28 % of the kernel's
 // duration was its tail, workgroups waiting for their slowest walker while the rest of the chip had drained.  The
 // random-number counters name the WALKER (row index + walker_base), never the slot, so which slot walks which row
-// changes nothing in the results.
+// changes nothing in the results.  The order in which the rows are taken is the host's (w.order): it hands the second
+// part of a walk out longest-expected first, from what every row cost in the first part (w.cost, rvll_api.hip).
 // FAT = false: the prior stage evaluates Beta / Gamma quantiles by their verified tables only (rvll_tile.h,
 // prior_heavy_slim).  A walker whose candidate needs anything else stops at the START of that move and reports the
 // number of completed moves in steps_done; the host finishes those walkers with the FAT instantiation (full solvers
@@ -80,23 +81,29 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
     int* gold    = gid + PB;                                // [PB] ... the row that has just finished there (to be sent home)
     int* refill  = gold + PB;                               // [PB] 0 / 1: send gold home and load gid / 2: send gold home, slot stays empty
     int* acc_g   = refill + PB;                             // [PB] row of the walker whose candidate was accepted (= gid then)
-    int* nact_s  = acc_g + PB;                              // [3]  active walkers, tile slots, slots to refill of this iteration
+    int* cost_of = acc_g + PB;                              // [PB] candidates the slot's current row has used in this launch
+    int* nact_s  = cost_of + PB;                            // [3]  active walkers, tile slots, slots to refill of this iteration
     int* wrapped_s = nact_s + 3;                            // [D]  circular parameters
     const double* chol = chol_in_lds ? chol_s : w.chol;
     const TileLds L = tile_views(a, smem);                  // the tile's results are read back from LDS (tile_point_result)
     const double one_below = 0.99999999999999988898;        // nextafter(1, 0)
 
-    for (int i = tid; i < nw * D; i += kThreads) wu[i] = w.u[w0 * D + i];
+    // the k-th row to be handed out (k: position in the host's order, or the row itself)
+    auto row_at = [&](long long k) -> int { return w.order ? w.order[k] : (int)k; };
+    for (int i = tid; i < nw * D; i += kThreads) wu[i] = w.u[(long long)row_at(w0 + i / D) * D + i % D];
     if (chol_in_lds) for (int i = tid; i < D * D; i += kThreads) chol_s[i] = w.chol[i];
     for (int i = tid; i < D; i += kThreads) wrapped_s[i] = w.wrapped[i];
     for (int i = tid; i < nw; i += kThreads) {
-        wl[i] = w.logl[w0 + i]; state[i] = 0; round_of[i] = 0; refill[i] = 0; gid[i] = (int)(w0 + i);
-        step_of[i] = w.step_start ? w.step_start[w0 + i] : 0;
+        const int g = row_at(w0 + i);
+        wl[i] = w.logl[g]; state[i] = 0; round_of[i] = 0; refill[i] = 0; gid[i] = g; cost_of[i] = 0;
+        step_of[i] = w.step_start ? w.step_start[g] : 0;
     }
     __syncthreads();
     // ---- the bookkeeping thread's helpers ----
     // tile slots of the next iteration: every active walker one, the free ones dealt out evenly, at most spec_max per
-    // walker and never past the move's last round
+    // walker and never past the move's last round.  (Dealt by each row's own rejection rate instead — the j-th slot of a
+    // walker is used with probability p^(j-1) — 0.5 % more of the evaluated slots were used and the kernel was 3 %
+    // slower: the dealer runs on one thread while the other waves wait.)
     auto deal_slots = [&](const int* act, int n) {
         const int base = n ? nw / n : 0, rem = n ? nw % n : 0;
         int f = 0;
@@ -113,11 +120,13 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
     bool queue_empty = false;
     auto next_row = [&]() -> int {
         while (!queue_empty) {
-            const long long q = qbase + (long long)atomicAdd(w.queue, 1ull);
-            if (q >= w.K) { queue_empty = true; break; }
+            const long long k = qbase + (long long)atomicAdd(w.queue, 1ull);
+            if (k >= w.K) { queue_empty = true; break; }
+            const int q = row_at(k);
             const int ss = w.step_start ? w.step_start[q] : 0;
-            if (ss < w.nsteps) return (int)q;
+            if (ss < w.nsteps) return q;
             if (w.steps_done) w.steps_done[q] = ss;
+            if (w.cost) w.cost[q] = 0;
         }
         return -1;
     };
@@ -125,6 +134,8 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
     // the slot also loads the row it takes over; returns whether the slot stays in the list
     auto retire = [&](int pl) -> bool {
         gold[pl] = gid[pl];
+        used_of[pl] = cost_of[pl];                          // (carried to the top of the next iteration, where the row goes home)
+        cost_of[pl] = 0;
         const int q = next_row();
         refill[pl] = q >= 0 ? 1 : 2;
         if (q < 0) return false;
@@ -164,7 +175,11 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
                 if (!r) continue;
                 const long long go = gold[pl];
                 w.u[go * D + k] = wu[i];
-                if (k == 0) { w.logl[go] = wl[pl]; if (w.steps_done) w.steps_done[go] = step_of[pl]; }
+                if (k == 0) {
+                    w.logl[go] = wl[pl];
+                    if (w.steps_done) w.steps_done[go] = step_of[pl];
+                    if (w.cost) w.cost[go] = used_of[pl];
+                }
                 if (r == 1) {
                     const long long gn = gid[pl];
                     wu[i] = w.u[gn * D + k];
@@ -293,6 +308,7 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
             for (int ai = 0; ai < nact; ++ai) {
                 const int pl = act[ai];
                 calls += (unsigned long long)used_of[pl];
+                cost_of[pl] += used_of[pl];
                 if (state[pl] == 2) { state[pl] = 0; step_of[pl] += 1; }
                 if (step_of[pl] < w.nsteps && state[pl] != 3) { act_next[n++] = pl; continue; }
                 ++nr;
@@ -309,7 +325,7 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
         const int pl = (act0 + (max_iters & 1) * PB)[i / D], k = i % D;
         const long long g = gid[pl];
         w.u[g * D + k] = wu[pl * D + k];
-        if (k == 0) { w.logl[g] = wl[pl]; if (w.steps_done) w.steps_done[g] = step_of[pl]; }
+        if (k == 0) { w.logl[g] = wl[pl]; if (w.steps_done) w.steps_done[g] = step_of[pl]; if (w.cost) w.cost[g] = cost_of[pl]; }
     }
     if (tid == kThreads - 1 && calls) atomicAdd(w.ncalls, calls);
     if (tid == kThreads - 1 && slots && w.nslots) atomicAdd(w.nslots, slots);
@@ -328,7 +344,25 @@ size_t walk_lds_bytes(const LoglikeArgs& a)
 {
     const size_t base = (loglike_lds_bytes(a) + 15) & ~(size_t)15;
     return base + sizeof(double) * ((size_t)5 * a.PB * a.D + 4 * a.PB + (a.D <= kWalkCholLds ? a.D * a.D : 0)) +
-           sizeof(int) * (14 * a.PB + 3 + a.D) + 16;
+           sizeof(int) * (15 * a.PB + 3 + a.D) + 16;
+}
+
+// workgroups of the walk kernel the given number of compute units holds at once (0: the query failed)
+long long slice_walk_resident_blocks(const LoglikeArgs& a, bool fat, int cus)
+{
+    const size_t lds = walk_lds_bytes(a);
+    int occ = 0;
+    hipError_t e;
+#define RVLL_WALK_OCC(PREC)                                                                                          \
+    e = fat ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (slice_walk_kernel<PREC, true>), kThreads, lds)     \
+            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (slice_walk_kernel<PREC, false>), kThreads, lds)
+    switch (a.precision) {
+    case RVLL_PREC_MIXED: RVLL_WALK_OCC(RVLL_PREC_MIXED); break;
+    case RVLL_PREC_FP32:  RVLL_WALK_OCC(RVLL_PREC_FP32); break;
+    default:              RVLL_WALK_OCC(RVLL_PREC_FP64); break;
+    }
+#undef RVLL_WALK_OCC
+    return e == hipSuccess ? (long long)std::max(1, occ) * cus : 0;
 }
 
 hipError_t launch_slice_walk(const LoglikeArgs& a, const WalkArgs& w, bool fat, int max_cus, hipStream_t stream)
