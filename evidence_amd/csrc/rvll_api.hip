@@ -152,7 +152,7 @@ void dev_free(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
 constexpr int kMaxLanes = 4;
 // rvll_loglike_batch: host batches from kSplitMinPoints on go up in overlapped chunks of about kSplitChunkPoints
 constexpr long long kSplitMinPoints = 16384, kSplitChunkPoints = 16384, kSplitMaxChunks = 8;   // profiles/r02_split_probe.txt
-constexpr int kWalkWords = 8;                 // counters of the walk kernel: calls, tile slots, 4 phase bins + workgroups (diagnostic build)
+constexpr int kWalkWords = 10;                // counters of the walk kernel: calls, tile slots, 4 phase bins + workgroups (diagnostic build)
 constexpr long long kFusedMaxPoints = 4096;   // rvll_prior_loglike_batch: one launch up to here, two beyond
 
 struct rvll_handle {
@@ -232,7 +232,7 @@ struct rvll_handle {
     int32_t *d_walk_cost = nullptr, *d_walk_order = nullptr;                            // [walk_cap] each (two-part walks)
     int walk_spec = 4;                          // candidates a walker may evaluate ahead per iteration (rvll_set_walk_speculation)
     long long walk_evaluated = 0;               // tile slots the last rvll_slice_walk evaluated (>= its ncalls)
-    unsigned long long walk_phase[5] = {};      // diagnostic build (make walktrace): 100 MHz ticks per phase, summed over workgroups; workgroups
+    unsigned long long walk_phase[6] = {};      // diagnostic build (make walktrace): 100 MHz ticks per phase, summed over workgroups; workgroups
 
     hipEvent_t marks[2] = {nullptr, nullptr};   // rvll_dev_mark: HIP events on lane 0's stream
 
@@ -1590,7 +1590,7 @@ int rvll_slice_walk(rvll_handle* h, double* cube, double* theta, double* logl, i
     HIP_TRY(hipStreamSynchronize(st));
     n = evaluated[0];
     h->walk_evaluated = (long long)evaluated[1];
-    for (int k = 0; k < 5; ++k) h->walk_phase[k] = evaluated[2 + k];
+    for (int k = 0; k < 6; ++k) h->walk_phase[k] = evaluated[2 + k];
     unsigned long long total = n;
     if (slim) {
         std::vector<int32_t> ids, start;
@@ -1627,7 +1627,7 @@ int rvll_slice_walk(rvll_handle* h, double* cube, double* theta, double* logl, i
             HIP_TRY(hipStreamSynchronize(st));
             total += evaluated[0];
             h->walk_evaluated += (long long)evaluated[1];
-            for (int k = 0; k < 5; ++k) h->walk_phase[k] += evaluated[2 + k];
+            for (int k = 0; k < 6; ++k) h->walk_phase[k] += evaluated[2 + k];
             for (size_t j = 0; j < M; ++j) {
                 memcpy(cube + (size_t)ids[j] * D, &su[j * D], sizeof(double) * D);
                 memcpy(theta + (size_t)ids[j] * D, &sth[j * D], sizeof(double) * D);
@@ -1656,10 +1656,10 @@ int rvll_slice_walk_evaluated(rvll_handle* h, int64_t* evaluated)
     return RVLL_OK;
 }
 
-int rvll_slice_walk_phases(rvll_handle* h, uint64_t out[5])
+int rvll_slice_walk_phases(rvll_handle* h, uint64_t out[6])
 {
     if (!h || !out) return fail(RVLL_E_INVALID, "null argument");
-    for (int k = 0; k < 5; ++k) out[k] = h->walk_phase[k];
+    for (int k = 0; k < 6; ++k) out[k] = h->walk_phase[k];
     return RVLL_OK;
 }
 

@@ -333,6 +333,7 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
     if (tid == 0 && w.nslots) {
         for (int k = 0; k < 4; ++k) atomicAdd(w.nslots + 1 + k, ph[k]);
         atomicAdd(w.nslots + 5, 1ull);
+        atomicMax(w.nslots + 6, ph[0] + ph[1] + ph[2] + ph[3]);         // the longest workgroup life of the launch(es)
     }
 #endif
 #undef WALK_STAMP

@@ -343,7 +343,7 @@ class GpuRVModel:
 
     def slice_walk_phases(self):
         """Diagnostic library build only (include/rvll.h): ticks per phase of the last slice_walk, summed over workgroups."""
-        out = (C.c_uint64 * 5)()
+        out = (C.c_uint64 * 6)()
         _abi.check(self._lib.rvll_slice_walk_phases(self._h, out))
         return [int(v) for v in out]
 

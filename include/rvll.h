@@ -242,8 +242,9 @@ int rvll_set_walk_speculation(rvll_handle* h, int32_t max_ahead);
 int rvll_slice_walk_evaluated(rvll_handle* h, int64_t* evaluated);
 /* Diagnostic build only (make -C evidence_amd/csrc walktrace; all zeros otherwise): where the workgroups of the last
  * rvll_slice_walk spent their time — 100 MHz ticks summed over workgroups for [0] directions + chord limits,
- * [1] candidates, [2] prior transform + log-L tile, [3] accept / copy / bookkeeping; [4] = number of workgroups. */
-int rvll_slice_walk_phases(rvll_handle* h, uint64_t out[5]);
+ * [1] candidates, [2] prior transform + log-L tile, [3] accept / copy / bookkeeping; [4] = number of workgroups;
+ * [5] = the longest workgroup life, in ticks. */
+int rvll_slice_walk_phases(rvll_handle* h, uint64_t out[6]);
 
 /* ---- scalar-callback latency ------------------------------------------------------------------------- */
 /* PolyChord's loglike(theta) is irreducibly scalar (evidence/polychord/__init__.py:166-171): one theta per call.

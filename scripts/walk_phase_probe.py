@@ -47,7 +47,7 @@ with GpuRVModel(w.fixedpardict, w.table, w.parnames, priordict=w.priordict()) as
         if ph[4]:
             names = ("directions + chord limits", "candidates", "prior transform + log-L tile", "accept / copy / bookkeeping")
             tot_t = sum(ph[:4])
-            print("    phase clock (diagnostic build): mean workgroup life %.2f ms; " % (tot_t / ph[4] * 1e-5) +
+            print("    phase clock (diagnostic build): workgroup life mean %.2f ms, longest %.2f ms; " % (tot_t / ph[4] * 1e-5, ph[5] * 1e-5) +
                   ", ".join(f"{nm} {100 * v / tot_t:.1f} %" for nm, v in zip(names, ph[:4])), flush=True)
 
     # the same bookkeeping over a nested-sampling run (bench.py's end-to-end configuration)
