@@ -53,3 +53,20 @@ def test_the_in_repo_driver_starts_from_the_reference_defaults():
     with pytest.raises(StopIteration):
         run_nested_slice(prior, loglike, 2, walker=walker)
     assert seen == {"nlive": 50, "nsteps": 6}
+
+
+def test_the_samplers_sort_is_the_stable_sort_whatever_route_it_takes():
+    """nested._stable_argsort goes through the vectorised unstable sort only when that provably gives the stable
+    permutation (no equal neighbours in sorted order, no NaN)."""
+    import numpy as np
+    from evidence_amd.nested import _stable_argsort
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=5000)
+    assert np.array_equal(_stable_argsort(x), np.argsort(x, kind="stable"))
+    x[[5, 7, 4000]] = -1e30                      # ties (several invalid orbits): the stable order of equal keys matters
+    x[100] = x[200]
+    assert np.array_equal(_stable_argsort(x), np.argsort(x, kind="stable"))
+    x[9] = np.nan
+    x[4999] = np.nan
+    assert np.array_equal(_stable_argsort(x), np.argsort(x, kind="stable"))
+    assert _stable_argsort(np.empty(0)).size == 0
