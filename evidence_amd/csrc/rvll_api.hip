@@ -1242,7 +1242,11 @@ int rvll_loglike_batch(rvll_handle* h, const double* theta, int64_t B, double* l
     if (!theta || !logL) return fail(RVLL_E_INVALID, "theta/logL is null");
     const size_t nin = sizeof(double) * (size_t)B * (size_t)h->L.ndim;
     const size_t nout = (sizeof(double) + sizeof(int32_t)) * (size_t)B;
-    if (nin <= 64 * 1024 && nout <= 64 * 1024) {
+    // theta rows that fit the pinned block (6898 points at 19 parameters) go there by memcpy and are read by the kernel
+    // over PCIe: 10 us less than an upload command at 512 .. 4096 points (RVLL_ZERO_COPY_IN_KB: measurement switch)
+    size_t zc_in_max = rvll_handle::kPinBytes;
+    if (const char* e = getenv("RVLL_ZERO_COPY_IN_KB")) zc_in_max = std::min((size_t)std::max(0, atoi(e)) * 1024, rvll_handle::kPinBytes);
+    if (nin <= zc_in_max && nout <= rvll_handle::kPinBytes) {
         // scalar / small-batch callback: zero-copy.  The kernel reads theta straight from mapped pinned host
         // memory and writes log-L and flags back into it — no copy commands, one launch, one sync.
         int rc = use_device(h);
@@ -1276,6 +1280,11 @@ int rvll_loglike_batch(rvll_handle* h, const double* theta, int64_t B, double* l
         // on an error in the middle of the loop, copies from the caller's buffers may still be in flight on either
         // stream: wait for both before handing the buffers back
         auto settle = [&]() { (void)hipStreamSynchronize(h->lanes[0]); (void)hipStreamSynchronize(h->lanes[1]); };
+        // results that fit the pinned block leave the kernels as stores into mapped host memory (as in the small-batch
+        // path): no download commands behind the last kernel, one memcpy on the host
+        const bool out_pinned = nout <= rvll_handle::kPinBytes && !getenv("RVLL_NO_PINNED_OUT");
+        double* out_l = out_pinned ? static_cast<double*>(h->pin_out_dev) : h->d_logL2[0];
+        int32_t* out_f = out_pinned ? reinterpret_cast<int32_t*>(static_cast<double*>(h->pin_out_dev) + B) : h->d_flags2[0];
         for (int c = 0; c < nsplit; ++c) {
             const long long lo = B * c / nsplit, hi = B * (c + 1) / nsplit;
             hipStream_t st = h->lanes[c & 1];
@@ -1284,14 +1293,38 @@ int rvll_loglike_batch(rvll_handle* h, const double* theta, int64_t B, double* l
               if (err_ != hipSuccess) { settle(); HIP_TRY(err_); } }
             rvll::LoglikeArgs a;
             int cu = 0;
-            rc = build_args(h, h->d_theta + lo * D, h->d_logL2[0] + lo, h->d_flags2[0] + lo, hi - lo, &a, &cu);
+            rc = build_args(h, h->d_theta + lo * D, out_l + lo, out_f + lo, hi - lo, &a, &cu);
             if (rc) { settle(); return rc; }
             { const hipError_t err_ = launch_form(a, cu, st); if (err_ != hipSuccess) { settle(); HIP_TRY(err_); } }
         }
         HIP_TRY(hipStreamSynchronize(h->lanes[1]));
         h->theta_async = false;
         h->logl_last = 0;
-        return rvll_dev_download(h, B, nullptr, logL, flags);
+        if (!out_pinned) return rvll_dev_download(h, B, nullptr, logL, flags);
+        HIP_TRY(hipStreamSynchronize(h->lanes[0]));
+        memcpy(logL, h->pin_out, sizeof(double) * (size_t)B);
+        if (flags) memcpy(flags, static_cast<char*>(h->pin_out) + sizeof(double) * (size_t)B, sizeof(int32_t) * (size_t)B);
+        return RVLL_OK;
+    }
+    if (nout <= rvll_handle::kPinBytes && !getenv("RVLL_NO_PINNED_OUT")) {
+        // one upload, one launch whose results are stores into mapped pinned host memory, one synchronisation
+        int rc = rvll_dev_reserve(h, B);
+        if (rc) return rc;
+        rc = sync_other_lanes(h);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(h->compute));     // the pinned block may still be read by an earlier call's copy
+        HIP_TRY(hipMemcpyAsync(h->d_theta, theta, nin, hipMemcpyHostToDevice, h->compute));
+        double* out_l = static_cast<double*>(h->pin_out_dev);
+        rvll::LoglikeArgs a;
+        int cu = 0;
+        rc = build_args(h, h->d_theta, out_l, reinterpret_cast<int32_t*>(out_l + B), B, &a, &cu);
+        if (rc) { (void)hipStreamSynchronize(h->compute); return rc; }
+        { const hipError_t err_ = launch_form(a, cu, h->compute); if (err_ != hipSuccess) { (void)hipStreamSynchronize(h->compute); HIP_TRY(err_); } }
+        HIP_TRY(hipStreamSynchronize(h->compute));
+        h->theta_async = false;
+        memcpy(logL, h->pin_out, sizeof(double) * (size_t)B);
+        if (flags) memcpy(flags, static_cast<char*>(h->pin_out) + sizeof(double) * (size_t)B, sizeof(int32_t) * (size_t)B);
+        return RVLL_OK;
     }
     int rc = rvll_dev_upload_theta(h, theta, B);
     if (rc) return rc;

@@ -28,7 +28,10 @@ def test_cu_form_is_bit_identical_to_tiles(gpu_required, cfg, n):
     theta = w.sample_theta(n, seed=300 + cfg)
     with GpuRVModel(w.fixedpardict, w.table, w.parnames) as m:
         got = _both(m, theta)
-        tm = m.dev_time_loglike(n, warmup=0, iters=1) if n >= 4096 else None
+        tm = None
+        if n >= 4096:
+            m.dev_upload_theta(theta)
+            tm = m.dev_time_loglike(n, warmup=0, iters=1)
     assert np.array_equal(got["tile"][0], got["cu"][0])
     assert np.array_equal(got["tile"][1], got["cu"][1])
     assert np.isfinite(got["cu"][0]).all()
