@@ -961,11 +961,14 @@ int rvll_dev_download(rvll_handle* h, int64_t B, double* theta, double* logL, in
             return RVLL_OK;
         }
         if (theta) {
-            // A large device-to-host copy into PAGEABLE memory crawls (40 MB of theta: 20 ms, 2 GB/s, whatever the
-            // chunking of the call — profiles/r02_split_probe.txt), while the same bytes into pinned memory move at
-            // PCIe speed: go through the two 1 MiB pinned staging buffers, the copy of chunk i+1 under the memcpy of
-            // chunk i.
-            constexpr size_t kDirectMax = 8u << 20, kChunk = rvll_handle::kPinBytes;
+            // A device-to-host copy into pageable memory runs at 50 GB/s once the runtime has pinned the destination
+            // range and cached that — which it cannot for a range it has never seen: 38 MB of theta into a fresh numpy
+            // array take 20-28 ms (1.5 GB/s), and numpy arrays above 32 MB are fresh mappings every time (glibc's mmap
+            // threshold stops growing there; below it the heap hands the same block out again and the copy is fast:
+            // profiles/r02_d2h_probe.txt).  From 32 MB on the rows therefore go through the two 1 MiB pinned blocks, the
+            // copy of chunk i+1 under the memcpy of chunk i: 6 ms for those 38 MB.  Below, directly (the staged route
+            // costs 3x there).
+            constexpr size_t kDirectMax = (32u << 20) - 1, kChunk = rvll_handle::kPinBytes;
             if (nt <= kDirectMax) {
                 HIP_TRY(hipMemcpyAsync(theta, h->d_theta, nt, hipMemcpyDeviceToHost, h->compute));
             } else {
@@ -1341,6 +1344,21 @@ int rvll_prior_batch(rvll_handle* h, const double* cube, int64_t B, double* thet
     if (B == 1 && h->srv_enabled && cube && theta) return scalar_call(h, rvll::kServerPrior, cube, nullptr, nullptr, theta);
     if (B == 0) return use_device(h);
     if (!cube || !theta) return fail(RVLL_E_INVALID, "cube/theta is null");
+    const size_t nrow = sizeof(double) * (size_t)B * (size_t)h->L.ndim;
+    if (nrow <= 384 * 1024 && !getenv("RVLL_NO_PINNED_OUT")) {
+        // a vectorized prior callback of up to 2586 points (19 parameters; beyond, the two host memcpys cost more than they save): the prior kernels read the cube from and write
+        // theta to mapped pinned host memory — no copy command in either direction
+        int rc = use_device(h);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(h->compute));
+        memcpy(h->pin_in, cube, nrow);
+        rvll::PriorArgs a{static_cast<const double*>(h->pin_in_dev), static_cast<double*>(h->pin_out_dev), (long long)B,
+                          h->L.ndim, h->d_priors, h->d_heavy, h->n_heavy};
+        HIP_TRY(rvll::launch_prior(a, h->compute));
+        HIP_TRY(hipStreamSynchronize(h->compute));
+        memcpy(theta, h->pin_out, nrow);
+        return RVLL_OK;
+    }
     int rc = rvll_dev_upload_cube(h, cube, B);
     if (rc) return rc;
     rc = rvll_dev_prior(h, B);
@@ -1360,10 +1378,9 @@ int rvll_prior_loglike_batch(rvll_handle* h, const double* cube, int64_t B,
         return scalar_call(h, rvll::kServerPriorLogLike, cube, logL, flags, theta_out);
     const size_t nin = sizeof(double) * (size_t)B * (size_t)h->L.ndim;
     const size_t nout = (sizeof(double) + sizeof(int32_t)) * (size_t)B;
-    if (nin <= 64 * 1024 && nout <= 64 * 1024 && h->all_direct) {
-        // small batch (a sampler's proposal round): the fused kernel reads the cube from mapped pinned host
-        // memory, theta goes to HBM, log-L and flags are written back zero-copy; theta returns with one copy
-        // command into the same pinned block
+    if (nin + nout + 16 <= rvll_handle::kPinBytes && h->all_direct && !getenv("RVLL_NO_PINNED_OUT")) {
+        // a sampler's proposal round (up to 6393 points at 19 parameters): the fused kernel reads the cube from mapped
+        // pinned host memory and stores theta, log-L and flags into it — no copy command in either direction
         int rc = rvll_dev_reserve(h, B);
         if (rc) return rc;
         HIP_TRY(hipStreamSynchronize(h->compute));
@@ -1375,11 +1392,14 @@ int rvll_prior_loglike_batch(rvll_handle* h, const double* cube, int64_t B,
         rvll::LoglikeArgs a;
         rc = build_args(h, h->d_theta, out_l, out_f, B, &a);
         if (rc) return rc;
-        make_fused(h, static_cast<const double*>(h->pin_in_dev), h->d_theta, &a);
+        // (flags end on a multiple of 4 bytes; theta starts on the next multiple of 16)
+        const size_t theta_off = (nout + 15) & ~(size_t)15;
+        if (theta_off + nin > rvll_handle::kPinBytes) return fail(RVLL_E_INVALID, "pinned block too small");
+        make_fused(h, static_cast<const double*>(h->pin_in_dev),
+                   reinterpret_cast<double*>(static_cast<char*>(h->pin_out_dev) + theta_off), &a);
         *h->pin_defer = 0;
         HIP_TRY(rvll::launch_prior_loglike(a, h->compute));
         char* host_out = static_cast<char*>(h->pin_out);
-        if (theta_out) HIP_TRY(hipMemcpyAsync(host_out + nout, h->d_theta, nin, hipMemcpyDeviceToHost, h->compute));
         HIP_TRY(hipStreamSynchronize(h->compute));
         if (__atomic_load_n(h->pin_defer, __ATOMIC_ACQUIRE) != 0) {
             // an element fell outside the slim stage's tables (rvll_tile.h): the full prior kernels take the batch
@@ -1395,7 +1415,7 @@ int rvll_prior_loglike_batch(rvll_handle* h, const double* cube, int64_t B,
         }
         memcpy(logL, host_out, sizeof(double) * (size_t)B);
         if (flags) memcpy(flags, host_out + sizeof(double) * (size_t)B, sizeof(int32_t) * (size_t)B);
-        if (theta_out) memcpy(theta_out, host_out + nout, nin);
+        if (theta_out) memcpy(theta_out, host_out + theta_off, nin);
         return RVLL_OK;
     }
     // measured (profiles/r01_split_probe.txt): two halves help from 16384 points (+15 %) to 65536 (+35 %); more chunks
