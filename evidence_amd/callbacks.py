@@ -57,12 +57,30 @@ def make_polychord_callbacks(model, low_latency: bool = False) -> Tuple[Callable
     return prior, loglike, ndim, nderived
 
 
-def make_ultranest_callbacks(model, vectorized: bool = False, low_latency: bool = False) -> Tuple[Callable, Callable]:
+def make_ultranest_callbacks(model, vectorized: bool = False, low_latency: bool = False, paired: bool = False) -> Tuple[Callable, Callable]:
     """(prior, loglike) for ultranest.ReactiveNestedSampler(parnames, loglike, prior, vectorized=...).
-    low_latency (scalar form only): as in make_polychord_callbacks."""
+    low_latency (scalar form only): as in make_polychord_callbacks.
+    paired (vectorized form): UltraNest evaluates loglike(p) on exactly the batch p = transform(u) it has just obtained;
+    with paired=True transform() runs the one-launch cube -> theta -> log-L call and loglike() answers from it when handed
+    that very batch (compared element by element; any other batch is evaluated as usual) — one round trip per proposal
+    round instead of two (1024 points: 42 us instead of 34 + 34)."""
     if low_latency and not vectorized:
         model.scalar_server(True)
-    if vectorized:
+    if vectorized and paired:
+        last = {"theta": None, "logl": None}
+
+        def prior(hypercubes):
+            theta, logl = model.prior_loglike_batch(np.asarray(hypercubes, dtype=np.float64))
+            last["theta"], last["logl"] = theta.copy(), logl
+            return theta
+
+        def loglike(thetas):
+            t = last["theta"]
+            x = np.asarray(thetas, dtype=np.float64)
+            if t is not None and x.shape == t.shape and np.array_equal(x, t):
+                return last["logl"].copy()
+            return model.log_likelihood_batch(x)
+    elif vectorized:
         def prior(hypercubes):
             return model.prior_transform_batch(np.asarray(hypercubes, dtype=np.float64))
 

@@ -357,6 +357,13 @@ def test_scalar_server_answers_polychord_style_calls(gpu_required):
         m.scalar_server(False)
         th2, ll2 = m.prior_loglike(cubes[3])
         assert np.array_equal(th1, th_want[3]) and np.array_equal(th2, th_want[3]) and ll1 == ll_want[3] and ll2 == ll_want[3]
+        # the vectorized pair: transform() evaluates log-L along the way, loglike() answers from it for that very batch
+        vprior, vloglike = make_ultranest_callbacks(m, vectorized=True, paired=True)
+        th = vprior(cubes)
+        assert np.array_equal(th, th_want) and np.array_equal(vloglike(th), ll_want)
+        assert np.array_equal(vloglike(th_want[:7]), ll_want[:7])              # another batch: evaluated as usual
+        th[0, 0] = th_want[1, 0]                                               # the caller's array is its own
+        assert np.array_equal(vloglike(th_want), ll_want)
     # both handles were destroyed with their servers possibly still polling: a new model works at once
     with GpuRVModel(case.fixed, case.table, case.parnames) as m3:
         assert np.array_equal(m3.log_likelihood_batch(case.theta[:10]), want[:10])
