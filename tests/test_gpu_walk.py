@@ -214,6 +214,18 @@ def test_speculation_and_the_walker_queue_change_nothing_in_the_results(gpu_requ
                     m.set_walk_speculation(ahead)
                     out = m.slice_walk(cube, theta, logl, lstar, chol, wr, nsteps=9, seed=5)
                     runs[(umax, queue, ahead)] = out + (m.slice_walk_evaluated(),)
+        # the full-solver instantiation through the queue and the two-part launch as well
+        m.set_slim_table_range(30.0)
+        m.set_walk_speculation(4)
+        monkeypatch.setenv("RVLL_WALK_FAT", "1")
+        monkeypatch.setenv("RVLL_WALK_QUEUE", "1")
+        fat_queue = m.slice_walk(cube, theta, logl, lstar, chol, wr, nsteps=9, seed=5)
+        monkeypatch.setenv("RVLL_WALK_PARTS", "1")
+        fat_one_part = m.slice_walk(cube, theta, logl, lstar, chol, wr, nsteps=9, seed=5)
+        monkeypatch.delenv("RVLL_WALK_FAT"); monkeypatch.delenv("RVLL_WALK_QUEUE"); monkeypatch.delenv("RVLL_WALK_PARTS")
+    for got in (fat_queue, fat_one_part):
+        ref = runs[(30.0, "0", 1)]
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2]) and got[3] == ref[3]
     for umax in (30.0, 1.0):
         ref = runs[(umax, "0", 1)]
         assert ref[4] == ref[3]                                    # no speculation: every evaluated slot is a call
