@@ -180,6 +180,7 @@ struct rvll_handle {
     int32_t* d_inst = nullptr;
     double*  d_linpar = nullptr;
     double   cte = 0.;
+    double   tmin = 0., tmax = 0.;              // range of the epoch times
 
     // priors
     bool have_priors = false;
@@ -446,6 +447,7 @@ int build_args(rvll_handle* h, const double* d_theta, double* d_logL, int32_t* d
     a.CH = std::min(h->chunk_items, std::max(rvll::kThreads, a.PB * h->Ne));
     a.CH = (a.CH + 1) & ~1;
     a.cte = h->cte;
+    a.tmin = h->tmin; a.tmax = h->tmax;
     if (cu_grid) {
         *cu_grid = choose_cu_form(h, B, &a);
         if (*cu_grid > 0) { *out = a; return RVLL_OK; }
@@ -581,6 +583,8 @@ int rvll_create(const rvll_layout* layout, const double* time, const double* vra
     h->L.linpar = h->linslots.data();
     h->Ne = n_epochs;
     h->cte = -0.5 * (double)n_epochs * std::log(2 * M_PI);          // rvmodel:77-78
+    h->tmin = h->tmax = time[0];
+    for (int j = 1; j < n_epochs; ++j) { h->tmin = std::min(h->tmin, time[j]); h->tmax = std::max(h->tmax, time[j]); }
 
 #define CREATE_TRY(expr)                                                             \
     do {                                                                             \

@@ -44,6 +44,7 @@ struct LoglikeArgs {
     int    PB;               // live points per workgroup
     int    CH;               // contribution slots in LDS (items per chunk)
     double cte;              // -0.5 * Ne * log(2*pi)
+    double tmin, tmax;       // range of the epoch table (a bound on |M| per planet is decoded from it: rvll_tile.h)
     // fused cube -> theta -> log-L form (launch_prior_loglike): the staging step applies the prior transform
     const double*      cube;        // [B, D] unit-cube rows, or nullptr for the plain form
     double*            theta_out;   // [B, D] the transformed parameters are also written here

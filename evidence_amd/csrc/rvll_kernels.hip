@@ -239,7 +239,7 @@ void keprv_kernel(const LoglikeArgs a, const double* times, int Nt, unsigned inc
             double E = M, s, c, dE;
             int steps = 0;
             do {
-                sincos_f64(E, s, c);
+                sincos_any(E, s, c);                  // the iteration may leave 2^50 at the clamp (rvll_math.h)
                 const double f = E - ec * s - M;
                 const double fp = 1 - ec * c;
                 const double En = E - div_exact(f, fp);

@@ -142,13 +142,123 @@ RVLL_HD void sincos_f64(double x, double& s_out, double& c_out, const SincosCons
     rc_lo = (s_lo & m) | (c_lo & ~m);
     rc_hi = (s_hi & m) | (c_hi & ~m);
 #endif
+#if defined(__HIP_DEVICE_COMPILE__)
+    // sign flips: hi ^= (quadrant bit moved to bit 31) — "and" and "xor" as ONE three-input bit operation each
+    // (v_bitop3_b32, truth table 0x78 = A ^ (B & C)); hipcc picks this form itself in some surroundings and two
+    // instructions each in others, which is two of the Newton loop's 43
+    const uint32_t q30 = q << 30;
+    rs_hi = __builtin_amdgcn_bitop3_b32(rs_hi, q30, 0x80000000u, 0x78);
+    rc_hi = __builtin_amdgcn_bitop3_b32(rc_hi, q30 + 0x40000000u, 0x80000000u, 0x78);
+#else
     rs_hi ^= (q & 2u) << 30;
     rc_hi ^= ((q + 1u) & 2u) << 30;
+#endif
     s_out = as_double(((uint64_t)rs_hi << 32) | rs_lo);
     c_out = as_double(((uint64_t)rc_hi << 32) | rc_lo);
 }
 
 RVLL_HD void sincos_f64(double x, double& s_out, double& c_out) { sincos_f64(x, s_out, c_out, sincos_consts()); }
+
+// ---- sin / cos of ANY finite double ---------------------------------------------------------------------------------
+// The reduction above is exact while x * 2/pi fits the 2^51 the magic-number rounding holds (and the second constant
+// keeps the error below 2^-60 far beyond the |M| ~ 1e4 of this path).  The reference's Newton iteration, however,
+// takes E far outside that at the 0.99 eccentricity clamp: started at E = M next to a zero of f' = 1 - e cos E it is
+// thrown out to |E| ~ 1e9 ... 1e22 (measured with glibc on the golden sweep, tests/golden/loglike_high_ecc.npz) and
+// finds its way back in 30 - 350 steps, and glibc reduces those arguments exactly.  An iteration fed anything else
+// there takes another way home and stops a step-width (~1e-8 .. 1e-4 in E) from where the reference stops — or, with
+// sin / cos that are not even a point of the unit circle, not at all.  So beyond 2^50 the argument is reduced the
+// long way (Payne - Hanek): x = M 2^e with M the 53-bit integer significand; of 2/pi only the 192 bits from position
+// e - 1 on can matter modulo 4 (everything before multiplies M 2^e to a multiple of 4); M times those 192 bits, modulo
+// 2^192, is x 2/pi modulo 4 to 2^-137: two bits of quadrant, 190 bits of fraction.  The fraction is renormalised
+// (double arguments come within 2^-61 of a multiple of pi/2, never closer), its leading 106 bits times pi/2 in
+// double-double give the reduced argument to better than an ulp.
+RVLL_HD uint64_t mulhi_u64(uint64_t a, uint64_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul64hi(a, b);
+#else
+    return (uint64_t)(((unsigned __int128)a * b) >> 64);
+#endif
+}
+// 2/pi: 64 zero bits (positions <= 0), then its first 1280 bits, most significant word first
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __constant__
+#endif
+static const uint64_t kTwoOverPiBits[21] = {
+    0x0000000000000000ull,
+    0xa2f9836e4e441529ull, 0xfc2757d1f534ddc0ull, 0xdb6295993c439041ull, 0xfe5163abdebbc561ull,
+    0xb7246e3a424dd2e0ull, 0x06492eea09d1921cull, 0xfe1deb1cb129a73eull, 0xe88235f52ebb4484ull,
+    0xe99c7026b45f7e41ull, 0x3991d639835339f4ull, 0x9c845f8bbdf9283bull, 0x1ff897ffde05980full,
+    0xef2f118b5a0a6d1full, 0x6d367ecf27cb09b7ull, 0x4f463f669e5fea2dull, 0x7527bac7ebe5f17bull,
+    0x3d0739f78a5292eaull, 0x6bfb5fb11f8d5d08ull, 0x56033046fc7b6babull, 0xf0cfbc209af4361dull};
+
+constexpr double kSincosFastMax = 1125899906842624.0;   // 2^50: below, sincos_f64's own reduction (exact first step, second
+                                                        // constant good to 2^-60 up to there); from here on, reduce_huge
+constexpr int    kSafeSteps = 8;                        // a Newton iterate cannot pass 2^50 before its 8th step (rvll_tile.h)
+constexpr double kExcursionM = 281474976710656.0;       // 2^48
+
+// |x| in [2^50, inf), finite (any |x| >= 2^-10 works): r in [-pi/4, pi/4] and the quadrant q (mod 4) with |x| = q pi/2 + r (mod 2 pi)
+RVLL_HD void reduce_huge(double x, double& r, uint32_t& q)
+{
+    const uint64_t bits = as_u64(x) & 0x7fffffffffffffffull;
+    const int ex = (int)(bits >> 52) - 1075;                           // |x| = M * 2^ex
+    const uint64_t M = (bits & 0x000fffffffffffffull) | 0x0010000000000000ull;
+    const int o = ex + 62;                                             // first table bit that matters (0-based, pad included)
+    const int wi = o >> 6, sh = o & 63;
+    const uint64_t a0 = kTwoOverPiBits[wi], a1 = kTwoOverPiBits[wi + 1], a2 = kTwoOverPiBits[wi + 2];
+    const uint64_t a3 = wi + 3 < 21 ? kTwoOverPiBits[wi + 3] : 0;
+    const uint64_t w0 = sh ? (a0 << sh) | (a1 >> (64 - sh)) : a0;
+    const uint64_t w1 = sh ? (a1 << sh) | (a2 >> (64 - sh)) : a1;
+    const uint64_t w2 = sh ? (a2 << sh) | (a3 >> (64 - sh)) : a2;
+    // (M * w0:w1:w2) mod 2^192
+    uint64_t p2 = M * w2;
+    uint64_t c2 = mulhi_u64(M, w2);
+    uint64_t p1 = M * w1;
+    uint64_t c1 = mulhi_u64(M, w1);
+    uint64_t p0 = M * w0;
+    p1 += c2;
+    c1 += p1 < c2 ? 1 : 0;
+    p0 += c1;
+    q = (uint32_t)(p0 >> 62);
+    // the 190-bit fraction, left-aligned in 192 bits; from 1/2 on, take it as a negative fraction of the next quadrant
+    uint64_t g0 = (p0 << 2) | (p1 >> 62), g1 = (p1 << 2) | (p2 >> 62), g2 = p2 << 2;
+    const bool neg = (g0 >> 63) != 0;
+    if (neg) {
+        q += 1;
+        g2 = ~g2 + 1;
+        g1 = ~g1 + (g2 == 0 ? 1 : 0);
+        g0 = ~g0 + ((g2 == 0 && g1 == 0) ? 1 : 0);
+    }
+    // renormalise: at most ~62 leading zeros for a double argument, a few more are harmless
+    int lz = 0;
+    if (g0 == 0) { g0 = g1; g1 = g2; g2 = 0; lz = 64; }
+    const int z = g0 ? __builtin_clzll(g0) : 63;
+    if (z) { g0 = (g0 << z) | (g1 >> (64 - z)); g1 = (g1 << z) | (g2 >> (64 - z)); }
+    lz += z;
+    const double fh = (double)(g0 >> 11);                              // leading 53 bits, exact
+    const double fl = (double)(((g0 & 0x7ffull) << 42) | (g1 >> 22)); // the next 53, exact
+    const double PIO2_HI = 1.57079632679489655800e+00, PIO2_LO = 6.12323399573676603587e-17;
+    const double hi = fh * PIO2_HI;
+    const double lo = __builtin_fma(fh, PIO2_HI, -hi) + (fh * PIO2_LO + fl * (PIO2_HI * 1.1102230246251565e-16));
+    double rr = ldexp(hi + lo, -53 - lz);                              // fh carries weight 2^(-53 - lz), fl 2^-53 of that
+    r = neg ? -rr : rr;
+}
+
+// sin and cos of any finite x (inf / nan: nan, like libm): the fast reduction below 2^50, the long one beyond
+RVLL_HD void sincos_any(double x, double& s_out, double& c_out, const SincosConsts& k)
+{
+    if (__builtin_fabs(x) < kSincosFastMax) { sincos_f64(x, s_out, c_out, k); return; }
+    if (!(__builtin_fabs(x) < __builtin_inf())) { s_out = c_out = __builtin_nan(""); return; }
+    double r, sr, cr;
+    uint32_t q;
+    reduce_huge(x, r, q);
+    sincos_kernel(r, sr, cr, k);
+    const double s = (q & 1u) ? cr : sr, c = (q & 1u) ? sr : cr;
+    const double ss = (q & 2u) ? -s : s, cc = ((q + 1u) & 2u) ? -c : c;
+    s_out = x < 0. ? -ss : ss;
+    c_out = cc;
+}
+RVLL_HD void sincos_any(double x, double& s_out, double& c_out) { sincos_any(x, s_out, c_out, sincos_consts()); }
 
 // n / d by reciprocal refinement.  v_rcp_f64 is accurate to 2^-24.4 (measured, scripts/rcp_probe.py): one
 // Newton step gives 2^-48, and the quotient with one residual correction q + (n - d q) y is then the

@@ -108,8 +108,8 @@ __host__ __device__ inline Carve carve(int PB, int D, int Np, int Ni, int nlin, 
     c.lay = o;     o += layout_doubles(Np, Ni, nlin);   // the layout structs, staged once per workgroup
     o = (o + 1) & ~1;
     c.contrib = o; o += CH;
-    c.ints = o;    // ints: nfail[1] ticket[1] pflags[PB] anyfail[PB] jfail[PB*Np]
-    const int nints = 2 + 2 * PB + PB * Np;
+    c.ints = o;    // ints: nfail[1] ticket[1] wide[1] pad[1] pflags[PB] anyfail[PB] jfail[PB*Np]
+    const int nints = 4 + 2 * PB + PB * Np;
     o += (nints + 1) / 2;
     c.total_doubles = o;
     return c;
@@ -249,6 +249,7 @@ struct ItemCtx {
     int* nfail;
     int* anyfail;
     int* jfail;
+    const int* wide;      // != 0: some planet of the tile has |M| beyond 2^48 (absurd period): no solve takes the shortcut
 };
 
 // One (point, epoch) item: returns ln sqrt(var) + res^2 / (2 var).
@@ -268,6 +269,7 @@ __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx&
     const double var = s2 + oj.y;                             // rvmodel:189-192 (oj.y = jitter^2 or 0)
 
     if (a.Np > 0) {
+        const bool wide = __builtin_amdgcn_readfirstlane(*cx.wide) != 0;
         bool point_failed = false;
         if constexpr (FAILCHECK) point_failed = cx.anyfail[pl] != 0;
         double ksum = 0.;
@@ -285,23 +287,49 @@ __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx&
                 // mean anomaly, rvmodel:459 — two roundings in (t-epoch), then mul, then add
                 const double M = p01.x * (t - p01.y) + p23.x;
                 // Newton, trueanomaly.c:17-33 — op-by-op, no contraction
-                double E = M, s, c, dE;
-                int steps = 0;
+                double E = M, s, c, dE = __builtin_inf();
 #ifdef RVLL_LOCAL_CONSTS
                 const SincosConsts kc = sincos_consts_pinned();     // loaded here, live through the loop (rvll_math.h)
 #else
                 const SincosConsts kc = sincos_consts();
 #endif
-                do {
-                    sincos_f64(E, s, c, kc);
-                    const double f  = E - ec * s - M;
-                    const double fp = 1 - ec * c;
-                    const double En = E - div_exact(f, fp);            // == f / fp, correctly rounded
-                    dE = En - E;
-                    E = En;
-                    ++steps;
-                } while (fabs(dE) > a.tol && steps < a.itmax);
-                if (steps >= a.itmax) {
+                // The first kSafeSteps iterations: an iterate cannot leave the range of the short sin / cos reduction
+                // (2^50, rvll_math.h) in fewer than eight steps — f' >= 0.01 and |f| <= |E - M| + e bound |E_k - M| by
+                // 99 (101^k - 1) / 100, and |M| < 2^48 by the bound the decode step takes per planet — so these run on it
+                // unconditionally (the flag is wave-uniform: a scalar branch).  Nearly every
+                // solve ends here (cfg3's priors: 2.9 steps on average, 0.01 % of the waves go past eight).
+                const bool shortcut = a.itmax > kSafeSteps && !wide;  // wave-uniform
+                if (shortcut) {
+                    int steps = 0;
+                    do {
+                        sincos_f64(E, s, c, kc);
+                        const double f  = E - ec * s - M;
+                        const double fp = 1 - ec * c;
+                        const double En = E - div_exact(f, fp);        // == f / fp, correctly rounded
+                        dE = En - E;
+                        E = En;
+                        ++steps;
+                    } while (fabs(dE) > a.tol && steps < kSafeSteps);
+                }
+                bool hit_itmax = false;
+                if (!(fabs(dE) <= a.tol)) {
+                    // Still going after eight steps (or not started: a tiny itmax, an absurd |M|).  At the eccentricity
+                    // clamp the reference's iteration is thrown out to |E| ~ 1e9 .. 1e22 and finds its way back in
+                    // 30 - 350 steps (rvll_math.h, sincos_any): from here on every sin / cos is reduced the long way
+                    // where its argument needs it — the same arithmetic, bit for bit, wherever it does not.
+                    int steps = shortcut ? kSafeSteps : 0;
+                    do {
+                        sincos_any(E, s, c, kc);
+                        const double f  = E - ec * s - M;
+                        const double fp = 1 - ec * c;
+                        const double En = E - div_exact(f, fp);
+                        dE = En - E;
+                        E = En;
+                        ++steps;
+                    } while (fabs(dE) > a.tol && steps < a.itmax);
+                    hit_itmax = steps >= a.itmax;
+                }
+                if (hit_itmax) {
                     atomicMin(&cx.jfail[pl * a.Np + ip], j);
                     atomicOr(&cx.anyfail[pl], 1);
                     atomicOr(cx.nfail, 1);
@@ -386,7 +414,7 @@ __device__ __forceinline__ void item_of(int i0, int lane, int Ne, int& pl, int& 
 // LDS views of one workgroup's tile (carve()).
 struct TileLds {
     double *theta_s, *pp, *ins, *dr, *lin, *acc, *lay, *contrib;
-    int *nfail, *ticket, *pflags, *anyfail, *jfail;
+    int *nfail, *ticket, *wide, *pflags, *anyfail, *jfail;
 };
 __device__ __forceinline__ TileLds tile_views(const LoglikeArgs& a, double* smem)
 {
@@ -395,7 +423,7 @@ __device__ __forceinline__ TileLds tile_views(const LoglikeArgs& a, double* smem
     L.theta_s = smem + cv.theta;  L.pp = smem + cv.pp;    L.ins = smem + cv.ins;  L.dr = smem + cv.dr;
     L.lin = smem + cv.lin;        L.acc = smem + cv.acc;  L.lay = smem + cv.lay;  L.contrib = smem + cv.contrib;
     int* ints = reinterpret_cast<int*>(smem + cv.ints);
-    L.nfail = ints;  L.ticket = ints + 1;  L.pflags = ints + 2;  L.anyfail = L.pflags + a.PB;  L.jfail = L.anyfail + a.PB;
+    L.nfail = ints;  L.ticket = ints + 1;  L.wide = ints + 2;  L.pflags = ints + 4;  L.anyfail = L.pflags + a.PB;  L.jfail = L.anyfail + a.PB;
     return L;
 }
 
@@ -409,7 +437,7 @@ __device__ __forceinline__ void tile_stage(const LoglikeArgs& __restrict__ a, co
     const int tid = threadIdx.x;
     for (int i = tid; i < npts; i += NT) { L.acc[i] = 0.; L.pflags[i] = 0; L.anyfail[i] = 0; }
     for (int i = tid; i < npts * a.Np; i += NT) L.jfail[i] = 0x7fffffff;
-    if (tid == 0) { L.nfail[0] = 0; L.ticket[0] = 0; }
+    if (tid == 0) { L.nfail[0] = 0; L.ticket[0] = 0; L.wide[0] = 0; }
     if constexpr (FUSED == kFusedSlim) __syncthreads();          // deferrals are OR-ed into pflags below
     if constexpr (FUSED != kFusedNone) {
         // cube_rows: the tile's unit-cube rows where the caller already holds them (the walk: in LDS), else a.cube
@@ -504,6 +532,11 @@ __device__ RVLL_DECODE_INLINE void tile_decode(const LoglikeArgs& __restrict__ a
         P[4] = K * co;
         P[5] = K * q * so;
         P[6] = K * (ecc * co);
+        // a bound on |M| over the epoch table: the solver's first eight steps skip the range check of their sin / cos
+        // arguments when it is below 2^48 for every planet of the tile (eval_item)
+        const double ep = d.epoch.idx >= 0 ? te : d.epoch.val;
+        const double mbound = fabs(kTwoPi / Pd) * fmax(fabs(a.tmax - ep), fabs(a.tmin - ep)) + fabs(ma0);
+        if (!(mbound < kExcursionM)) atomicOr(L.wide, 1);
         P[7] = 0.;
     }
     for (int pl = NT - 1 - tid; pl < npts; pl += NT) {
@@ -624,7 +657,7 @@ __device__ __forceinline__ __attribute__((flatten)) void loglike_tile(const Logl
     if constexpr (TRACE) { if (tid == 0) tr[DYN ? 3 : 1] = __builtin_amdgcn_s_memrealtime(); }
 
     // 3. items: flattened (point, epoch) pairs of this block, CH at a time
-    const ItemCtx cx{L.pp, L.ins, L.dr, L.lin, L.nfail, L.anyfail, L.jfail};
+    const ItemCtx cx{L.pp, L.ins, L.dr, L.lin, L.nfail, L.anyfail, L.jfail, L.wide};
     double* contrib = L.contrib;
     const int nitems = npts * a.Ne;
     // LDS windows are cut at point-local positions — whole points while a point fits the window, otherwise

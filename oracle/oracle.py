@@ -43,6 +43,8 @@ def load():
         lib.rvo_iteration_counts.restype = C.c_int
         lib.rvo_iteration_counts.argtypes = [C.POINTER(_abi.Layout), _dp, C.c_int, _dp, _ip]
         lib.rvo_max_threads.restype = C.c_int
+        lib.rvo_set_trig_perturb.restype = None
+        lib.rvo_set_trig_perturb.argtypes = [C.c_double]
         lib.rvo_kep_rv_batch.restype = C.c_int
         lib.rvo_kep_rv_batch.argtypes = [C.POINTER(_abi.Layout), _dp, C.c_long, _dp, C.c_int, C.c_uint, _dp]
         lib.rvo_fip_accumulate.argtypes = [_dp, _dp, C.c_int, _dp, _dp, C.c_long, C.c_int, _dp]
@@ -106,6 +108,23 @@ class OracleModel:
         if rc != 0:
             raise MemoryError("oracle allocation failed")
         return (out, flags) if return_flags else out
+
+    def conditioning(self, theta, nthreads=1, eps=2.0 ** -53):
+        """How far log-L moves (relative) when sin / cos inside the Newton loop are nudged by one unit in the last place
+        either way (rvo_set_trig_perturb): per row, max over the two signs.  Rows where this exceeds the parity bar are
+        rows whose reference value is an accident of the reference's libm."""
+        base = self.loglike(theta, nthreads)
+        worst = np.zeros_like(base)
+        try:
+            for p in (eps, -eps):
+                self.lib.rvo_set_trig_perturb(p)
+                got = self.loglike(theta, nthreads)
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    d = np.where(got == base, 0.0, np.abs(got - base) / np.maximum(np.abs(base), 1e-300))
+                worst = np.maximum(worst, d)
+        finally:
+            self.lib.rvo_set_trig_perturb(0.0)
+        return worst
 
     def kep_rv(self, theta, times, include_mask):
         theta = np.ascontiguousarray(np.atleast_2d(theta), dtype=np.float64)

@@ -44,6 +44,14 @@
 /* least one step; ecc clamped to 0.99 inside the solver only; on reaching   */
 /* itmax the call returns -1 immediately and leaves nu[i..n) untouched.      */
 /* iters (optional) receives the per-element Newton step counts.             */
+/* Conditioning probe (tests only): sin / cos inside the Newton loop are multiplied by 1 + rvo_trig_perturb.  At 0 (the
+ * default) the arithmetic is the reference's; at +-2^-53 it is what a libm that rounds the other way would give — where
+ * the result then moves by more than the parity bar, the reference's own value is an accident of its libm's last bit
+ * (Newton from E = M at the 0.99 clamp wanders before it settles, and the stop |dE| <= 1e-4 leaves E anywhere within
+ * ~1e-4 of the root where f' ~ 0.01). */
+static double rvo_trig_perturb = 0.;
+RVO_EXPORT void rvo_set_trig_perturb(double p) { rvo_trig_perturb = p; }
+
 RVO_EXPORT int rvo_trueanomaly(const double* M, int n, double ecc, double* nu,
                                int itmax, double tol, int32_t* iters)
 {
@@ -65,6 +73,29 @@ RVO_EXPORT int rvo_trueanomaly(const double* M, int n, double ecc, double* nu,
         }
         if (iters) iters[i] = steps;
         nu[i] = 2. * atan(sqrt((1. + ecc) / (1. - ecc)) * tan(cur / 2.));  /* :36 */
+    }
+    return 0;
+}
+
+/* The same solver with sin / cos nudged (rvo_set_trig_perturb): a separate function so that the one above compiles to
+ * exactly what it did — its bits depend even on whether the compiler fuses the sin and cos calls into one sincos. */
+static int trueanomaly_nudged(const double* M, int n, double ecc, double* nu, int itmax, double tol)
+{
+    const double pert = 1. + rvo_trig_perturb;
+    if (ecc > 0.99) ecc = 0.99;
+    for (int i = 0; i < n; ++i) {
+        const double m = M[i];
+        double cur = m, prev = m;
+        int steps = 0;
+        while (fabs(cur - prev) > tol || steps == 0) {
+            prev = cur;
+            const double f  = cur - ecc * (sin(cur) * pert) - m;
+            const double fp = 1 - ecc * (cos(cur) * pert);
+            cur = prev - f / fp;
+            steps += 1;
+            if (steps >= itmax) return -1;
+        }
+        nu[i] = 2. * atan(sqrt((1. + ecc) / (1. - ecc)) * tan(cur / 2.));
     }
     return 0;
 }
@@ -180,7 +211,8 @@ static double rvo_loglike_one(const rvo_problem* pb, const double* theta,
                 ma[j] = w * (pb->time[j] - q.epoch) + q.ma0;
             /* nu pre-zeroed (:488); return code ignored (:490-492) */
             memset(nu, 0, sizeof(double) * (size_t)Ne);
-            if (rvo_trueanomaly(ma, Ne, q.ecc, nu, L->itmax, L->tol, NULL) != 0)
+            if ((rvo_trig_perturb == 0. ? rvo_trueanomaly(ma, Ne, q.ecc, nu, L->itmax, L->tol, NULL)
+                                        : trueanomaly_nudged(ma, Ne, q.ecc, nu, L->itmax, L->tol)) != 0)
                 flag |= RVLL_FLAG_NONCONVERGED;
             const double ecw = q.ecc * cos(q.omega);
             for (int j = 0; j < Ne; ++j)                               /* :463 */

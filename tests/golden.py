@@ -63,8 +63,16 @@ def peg51_cases():
                  z[f"{m['name']}_logL"]) for m in meta]
 
 
+def high_ecc_case():
+    """Eccentricity sweep 0.90 .. 0.9925 of one planet (gen_golden.py, gen_high_ecc): the solver's sensitive corner."""
+    z = np.load(GOLDEN / "loglike_high_ecc.npz")
+    insts = [str(s) for s in z["insts"]]
+    fixed = {str(k): float(v) for k, v in zip(z["fixed_names"], z["fixed_values"])}
+    return Case("high_ecc_sweep", _table(z, "", insts), [str(s) for s in z["parnames"]], fixed, z["theta"], z["logL"])
+
+
 def all_loglike_cases():
-    return [config_case(c) for c in (1, 2, 3, 4, 5)] + edge_cases() + peg51_cases()
+    return [config_case(c) for c in (1, 2, 3, 4, 5)] + edge_cases() + peg51_cases() + [high_ecc_case()]
 
 
 def prior_sets():

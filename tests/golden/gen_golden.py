@@ -9,6 +9,7 @@ writes small fixtures (inputs + expected outputs) next to this file:
     loglike_51peg.npz/.json the shipped 51Peg example, both configs
     priors.npz/.json        .ppf of every working distribution on a q grid (§8c.4)
     keprv.npz/.json         kep_rv(exclude_planet) / modelk(planet) curves at arbitrary times (§8f.3)
+    loglike_high_ecc.npz    eccentricity sweep 0.90 .. 0.9925 (the solver's sensitive corner)
 
 The reference never travels to the GPU box; these fixtures do.  Dev-only shim:
 `numpy.int = int` (evidence/rvmodel/__init__.py:53 uses the alias numpy removed).
@@ -348,8 +349,39 @@ def gen_keprv():
     (HERE / "keprv.json").write_text(json.dumps(meta, indent=1))
 
 
+def gen_high_ecc():
+    """The solver's sensitive corner: Newton from E = M at eccentricities near the 0.99 clamp wanders before it settles
+    (6 .. 1159 steps) and amplifies any difference in an iterate.  A sweep of 10 eccentricities x 24 points on
+    a two-planet, two-instrument model (the second planet at a moderate eccentricity), log-L from the reference itself."""
+    rng = np.random.default_rng(2024)
+    table = small_table(21, 160, 2)
+    free = sorted(["planet1_k1", "planet1_period", "planet1_ecc", "planet1_omega", "planet1_ma0",
+                   "planet2_k1", "planet2_period", "planet2_ecc", "planet2_omega", "planet2_ma0",
+                   "ia_offset", "ia_jitter", "ib_offset", "ib_jitter"])
+    fixed = {"planet1_epoch": 50000.0, "planet2_epoch": 50007.0}
+    eccs = [0.90, 0.93, 0.95, 0.965, 0.975, 0.98, 0.985, 0.989, 0.9899, 0.9925]
+    rows = []
+    for e in eccs:
+        n = 24
+        th = {"planet1_k1": rng.uniform(1, 40, n), "planet1_period": rng.uniform(2, 300, n), "planet1_ecc": np.full(n, e),
+              "planet1_omega": rng.uniform(0, 2 * np.pi, n), "planet1_ma0": rng.uniform(0, 2 * np.pi, n),
+              "planet2_k1": rng.uniform(1, 20, n), "planet2_period": rng.uniform(5, 120, n),
+              "planet2_ecc": rng.beta(0.867, 3.03, n), "planet2_omega": rng.uniform(0, 2 * np.pi, n),
+              "planet2_ma0": rng.uniform(0, 2 * np.pi, n), "ia_offset": rng.uniform(-5, 5, n), "ia_jitter": rng.uniform(0, 6, n),
+              "ib_offset": rng.uniform(-5, 5, n), "ib_jitter": rng.uniform(0, 6, n)}
+        rows.append(np.stack([th[k] for k in free], axis=1))
+    theta = np.concatenate(rows)
+    logl = ref_loglike(table, free, fixed, theta)
+    np.savez_compressed(HERE / "loglike_high_ecc.npz", theta=theta, logL=logl, parnames=np.array(free),
+                        insts=np.array(table.insts), fixed_names=np.array(list(fixed)),
+                        fixed_values=np.array(list(fixed.values()), dtype=float), ecc_of_row=np.repeat(eccs, 24),
+                        **table_arrays("", table))
+    print(f"high ecc: {len(theta)} points, logL in [{logl.min():.3f}, {logl.max():.3f}]")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["configs", "edges", "51peg", "priors", "keprv"]
+    which = sys.argv[1:] or ["configs", "edges", "51peg", "priors", "keprv", "high_ecc"]
+    if "high_ecc" in which: gen_high_ecc()
     if "configs" in which: gen_configs()
     if "edges" in which: gen_edges()
     if "51peg" in which: gen_51peg()

@@ -5,6 +5,17 @@
 #include "rvll_special.h"
 #define HM extern "C" __attribute__((visibility("default")))
 HM void hm_sincos(const double* x, long n, double* s, double* c) { for (long i = 0; i < n; ++i) rvll::sincos_f64(x[i], s[i], c[i]); }
+HM void hm_sincos_any(const double* x, long n, double* s, double* c) { for (long i = 0; i < n; ++i) rvll::sincos_any(x[i], s[i], c[i]); }
+// the long reduction by itself (any |x| >= 1), so that it can be checked where the short one is valid too
+HM void hm_sincos_long(const double* x, long n, double* s, double* c) {
+    for (long i = 0; i < n; ++i) {
+        double r, sr, cr; uint32_t q;
+        rvll::reduce_huge(x[i], r, q);
+        rvll::sincos_kernel(r, sr, cr, rvll::sincos_consts());
+        const double a = (q & 1u) ? cr : sr, b = (q & 1u) ? sr : cr;
+        s[i] = ((q & 2u) ? -a : a) * (x[i] < 0 ? -1. : 1.);
+        c[i] = ((q + 1u) & 2u) ? -b : b;
+    } }
 HM void hm_ndtri(const double* p, long n, double* out) { for (long i = 0; i < n; ++i) out[i] = rvll::ndtri_f64(p[i]); }
 HM void hm_ndtri_cephes(const double* p, long n, double* out) { for (long i = 0; i < n; ++i) out[i] = rvll::ndtri_cephes(p[i]); }
 HM void hm_beta_ppf(const double* q, long n, double a, double b, double lbeta, double* out) { for (long i = 0; i < n; ++i) out[i] = rvll::beta_ppf(q[i], a, b, lbeta); }

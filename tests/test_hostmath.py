@@ -136,3 +136,38 @@ def test_tabulated_quantiles_equal_the_full_solver(hm):
     print(report)
     # the shapes the shipped configs use must qualify for the interpolation-only path
     assert [r[3] <= tol for r in report if r[:3] in (("beta", 0.867, 3.03), ("beta", 2, 5))] == [True, True]
+
+
+def test_sincos_of_any_finite_double(hm):
+    """sincos_any (rvll_math.h): the short reduction up to 2^50, the long (Payne - Hanek) one beyond, against glibc, which
+    reduces every argument exactly: <= 1.5 ulp of 1 over random arguments up to 1e300, at exact powers of two, around the
+    switch at 2^50, and at the doubles closest to multiples of pi/2 (where a short reduction loses everything) with their
+    RELATIVE accuracy kept; the long reduction by itself is also checked from 1 upwards, where the short one is valid too."""
+    rng = np.random.default_rng(12)
+    x = np.concatenate([
+        rng.uniform(-1, 1, 20000) * 10.0 ** rng.uniform(0, 300, 20000),
+        rng.uniform(-1, 1, 20000) * 2.0 ** rng.uniform(28, 56, 20000),
+        2.0 ** np.arange(0, 1024), -(2.0 ** np.arange(0, 1024)),
+        2.0 ** 50 + np.arange(-64, 65) * 0.25,
+        np.array([6381956970095103.0 * 2.0 ** 797, 5319372648326541416707072.0, 1e22, 2.343e22, -1.03e18]),
+        rng.integers(1, 2 ** 22, 5000) * np.pi,                      # the doubles next to multiples of pi: sin ~ 1e-10
+        rng.integers(1, 2 ** 22, 5000) * np.pi + np.pi / 2,          # ... and cos
+    ])
+    rs = np.array([math.sin(v) for v in x])
+    rc = np.array([math.cos(v) for v in x])
+    ulp = 2.0 ** -52
+    for fn, sel in (("hm_sincos_any", np.ones(x.size, bool)), ("hm_sincos_long", np.abs(x) >= 1.0)):
+        xs = np.ascontiguousarray(x[sel])
+        s, c = np.empty_like(xs), np.empty_like(xs)
+        getattr(hm, fn)(xs.ctypes.data_as(dp), C.c_long(xs.size), s.ctypes.data_as(dp), c.ctypes.data_as(dp))
+        es, ec = np.abs(s - rs[sel]), np.abs(c - rc[sel])
+        assert es.max() <= 1.5 * ulp, (fn, float(es.max() / ulp), float(xs[es.argmax()]))
+        assert ec.max() <= 1.5 * ulp, (fn, float(ec.max() / ulp), float(xs[ec.argmax()]))
+        if fn == "hm_sincos_long":                          # the long reduction keeps small results RELATIVELY accurate
+            tiny = np.abs(rs[sel]) < 1e-6                   # (the short one is absolute: 2^-60 per quadrant passed)
+            assert tiny.sum() > 100
+            assert np.max(es[tiny] / np.abs(rs[sel][tiny])) <= 4 * ulp
+    bad = np.array([np.inf, -np.inf, np.nan])
+    sb, cb = np.empty(3), np.empty(3)
+    hm.hm_sincos_any(bad.ctypes.data_as(dp), C.c_long(3), sb.ctypes.data_as(dp), cb.ctypes.data_as(dp))
+    assert np.isnan(sb).all() and np.isnan(cb).all()

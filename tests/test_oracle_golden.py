@@ -15,8 +15,13 @@ def test_oracle_matches_reference_golden(case):
     om = orc.OracleModel(case.layout, case.table, case.linpar_series)
     got = om.loglike(case.theta)
     err = golden.rel_err(got, case.logL)
-    # same libm-level operations as the reference; only numpy's SIMD cos/log kernels differ
-    assert err.max() <= 5e-13, (case.name, err.max(), int(err.argmax()))
+    # same libm-level operations as the reference; only numpy's SIMD cos/log kernels differ.  In the eccentricity sweep
+    # (239 of 240 rows bit-equal) one row at the 0.99 clamp, where Newton from E = M wanders before it settles, turns that
+    # last-bit difference into 2e-12: there the bar is the north star's 1e-10
+    tol = 1e-10 if case.name == "high_ecc_sweep" else 5e-13
+    assert err.max() <= tol, (case.name, err.max(), int(err.argmax()))
+    if case.name == "high_ecc_sweep":
+        assert np.count_nonzero(err > 5e-13) <= 2
 
 
 def test_known_answer_51peg():
@@ -72,3 +77,18 @@ def test_openmp_batch_equals_serial():
     a = om.loglike(case.theta, nthreads=1)
     b = om.loglike(case.theta, nthreads=4)
     assert np.array_equal(a, b)
+
+
+def test_the_references_value_is_conditioned_worse_than_the_bar_near_the_clamp():
+    """OracleModel.conditioning: log-L of the eccentricity sweep with every sin / cos of the Newton loop nudged by one
+    unit in the last place.  Up to e = 0.965 nothing moves beyond 1e-13; from 0.975 on individual rows move by 1e-11 ..
+    1e-9 — Newton from E = M wanders there before it settles, and where it stops depends on the last bit of libm.  This is
+    what "parity with the reference" can mean in that corner (tests/test_gpu_loglike.py)."""
+    case = golden.high_ecc_case()
+    z = np.load(golden.GOLDEN / "loglike_high_ecc.npz")
+    ecc = z["ecc_of_row"]
+    om = orc.OracleModel(case.layout, case.table)
+    cond = np.maximum(om.conditioning(case.theta, eps=-2.0 ** -53), om.conditioning(case.theta, eps=2.0 ** -52))
+    assert cond[ecc <= 0.965].max() <= 1e-13
+    assert 1e-11 <= cond[ecc >= 0.975].max() <= 5e-9
+    assert np.array_equal(om.loglike(case.theta), om.loglike(case.theta))          # and the probe leaves no trace
