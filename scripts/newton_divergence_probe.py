@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Where do the device's Newton iterates leave the reference's?  For the worst rows of the eccentricity-sweep fixture
-(tests/golden/loglike_high_ecc.npz) the solver is replayed on the host twice — sin / cos from libm, and from the device
-routine (rvll_debug_eval ops 0 / 1), everything else in IEEE double as both sides do it — epoch by epoch.  Run on the
-GPU box."""
+(tests/golden/loglike_high_ecc.npz) the solver is replayed on the host twice — sin / cos from numpy, and from the device's
+SHORT-reduction routine (rvll_debug_eval ops 0 / 1), everything else in IEEE double as both sides do it — epoch by epoch.
+This is the probe that found the excursions to |E| ~ 1e9 .. 1e22 at the 0.99 clamp: beyond 2^51 * pi/2 the
+short reduction returns sin / cos of another angle.  (The kernels now switch to the long reduction there; op 0 / 1 of
+rvll_debug_eval still show the short one.)  Run on the GPU box."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
