@@ -338,7 +338,7 @@ __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx&
                     // (s, c) are at the previous iterate; the accepted step |dE| <= tol:
                     // rotate instead of a third range reduction.
                     if (a.tol <= 1e-3) rotate_small(dE, s, c);
-                    else               sincos_f64(E, s, c);
+                    else               sincos_any(E, s, c, kc);
                     // K (cos(nu+w) + e cos w) with cos nu = (cos E - e)/(1 - e cos E),
                     // sin nu = sqrt(1-e^2) sin E/(1 - e cos E)  == trueanomaly.c:36 + rvmodel:463
                     const double den = __builtin_fma(-ec, c, 1.0);
@@ -361,17 +361,38 @@ __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx&
                     dE = En - E;
                     E = En;
                     ++steps;
-                } while (fabsf(dE) > tolf && steps < a.itmax);
+                } while (fabsf(dE) > tolf && steps < a.itmax && steps < kF32Steps);
+                if (fabsf(dE) > tolf && steps < a.itmax) {
+                    // not settled after kF32Steps: at the eccentricity clamp the iteration wanders far outside what a
+                    // float (or its one-step reduction) can follow — such a solve is done in double from the start,
+                    // as the parity mode does it (rare: cfg3's priors, 0.01 % of the waves)
+                    double Ed = M, sd, cd, dd;
+                    const SincosConsts kc = sincos_consts();
+                    steps = 0;
+                    do {
+                        sincos_any(Ed, sd, cd, kc);
+                        const double f  = Ed - ec * sd - M;
+                        const double fp = 1 - ec * cd;
+                        const double En = Ed - div_exact(f, fp);
+                        dd = En - Ed;
+                        Ed = En;
+                        ++steps;
+                    } while (fabs(dd) > a.tol && steps < a.itmax);
+                    if (steps < a.itmax) {
+                        sincos_any(Ed, sd, cd, kc);
+                        rv = div_fast(__builtin_fma(p45.x, cd - ec, -(p45.y * sd)), __builtin_fma(-ec, cd, 1.0)) + C0;
+                    }
+                } else if (steps < a.itmax) {
+                    sincos_f32(E, s, c);
+                    const float den = __builtin_fmaf(-ecf, c, 1.0f);
+                    const float num = __builtin_fmaf((float)p45.x, c - ecf, -((float)p45.y * s));
+                    rv = (double)(div_f32(num, den) + (float)C0);
+                }
                 if (steps >= a.itmax) {
                     atomicMin(&cx.jfail[pl * a.Np + ip], j);
                     atomicOr(&cx.anyfail[pl], 1);
                     atomicOr(cx.nfail, 1);
                     rv = p45.x + C0;
-                } else {
-                    sincos_f32(E, s, c);
-                    const float den = __builtin_fmaf(-ecf, c, 1.0f);
-                    const float num = __builtin_fmaf((float)p45.x, c - ecf, -((float)p45.y * s));
-                    rv = (double)(div_f32(num, den) + (float)C0);
                 }
             }
             ksum += rv;                                                     // rvmodel:383
