@@ -71,8 +71,16 @@ def high_ecc_case():
     return Case("high_ecc_sweep", _table(z, "", insts), [str(s) for s in z["parnames"]], fixed, z["theta"], z["logL"])
 
 
+def wild_case():
+    """Adversarial parameter ranges (gen_golden.py, gen_wild)."""
+    z = np.load(GOLDEN / "loglike_wild.npz")
+    insts = [str(s) for s in z["insts"]]
+    fixed = {str(k): float(v) for k, v in zip(z["fixed_names"], z["fixed_values"])}
+    return Case("wild_sweep", _table(z, "", insts), [str(s) for s in z["parnames"]], fixed, z["theta"], z["logL"])
+
+
 def all_loglike_cases():
-    return [config_case(c) for c in (1, 2, 3, 4, 5)] + edge_cases() + peg51_cases() + [high_ecc_case()]
+    return [config_case(c) for c in (1, 2, 3, 4, 5)] + edge_cases() + peg51_cases() + [high_ecc_case(), wild_case()]
 
 
 def prior_sets():

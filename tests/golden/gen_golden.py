@@ -10,6 +10,7 @@ writes small fixtures (inputs + expected outputs) next to this file:
     priors.npz/.json        .ppf of every working distribution on a q grid (§8c.4)
     keprv.npz/.json         kep_rv(exclude_planet) / modelk(planet) curves at arbitrary times (§8f.3)
     loglike_high_ecc.npz    eccentricity sweep 0.90 .. 0.9925 (the solver's sensitive corner)
+    loglike_wild.npz        adversarial parameter ranges (tiny / huge periods and amplitudes, invalid orbits, zero jitter)
 
 The reference never travels to the GPU box; these fixtures do.  Dev-only shim:
 `numpy.int = int` (evidence/rvmodel/__init__.py:53 uses the alias numpy removed).
@@ -379,8 +380,38 @@ def gen_high_ecc():
     print(f"high ecc: {len(theta)} points, logL in [{logl.min():.3f}, {logl.max():.3f}]")
 
 
+def gen_wild():
+    """Adversarial sweep: parameters drawn from far wider ranges than any prior would allow — periods 0.01 .. 1e5 d
+    (|M| up to 1e6 rad), amplitudes 1e-3 .. 1e4, (secos, sesin) over the whole unit disk and a little beyond (invalid
+    orbits), directly parametrised eccentricities from -0.1 to 1.1, huge offsets and drifts, jitters down to zero —
+    on a two-instrument model with one planet per parametrisation family; log-L from the reference itself."""
+    rng = np.random.default_rng(31337)
+    table = small_table(33, 120, 2)
+    free = sorted(["planet1_logk1", "planet1_logperiod", "planet1_secos", "planet1_sesin", "planet1_ml0",
+                   "planet2_k1", "planet2_period", "planet2_ecc", "planet2_omega", "planet2_ma0",
+                   "ia_offset", "ia_jitter", "ib_offset", "ib_jitter", "drift_lin", "drift_quad"])
+    fixed = {"planet1_epoch": 50000.0, "planet2_epoch": 50123.456}
+    n = 400
+    r = np.sqrt(rng.uniform(0, 1.1, n)); ang = rng.uniform(0, 2 * np.pi, n)
+    th = {"planet1_logk1": rng.uniform(np.log(1e-3), np.log(1e4), n), "planet1_logperiod": rng.uniform(np.log(0.01), np.log(1e5), n),
+          "planet1_secos": r * np.cos(ang), "planet1_sesin": r * np.sin(ang), "planet1_ml0": rng.uniform(-20, 20, n),
+          "planet2_k1": rng.choice([-1, 1], n) * 10 ** rng.uniform(-3, 4, n), "planet2_period": 10 ** rng.uniform(-2, 5, n),
+          "planet2_ecc": rng.uniform(-0.1, 1.1, n), "planet2_omega": rng.uniform(-10, 10, n), "planet2_ma0": rng.uniform(-50, 50, n),
+          "ia_offset": rng.normal(0, 1e3, n), "ia_jitter": np.where(rng.random(n) < 0.2, 0.0, 10 ** rng.uniform(-3, 2, n)),
+          "ib_offset": rng.normal(0, 10, n), "ib_jitter": 10 ** rng.uniform(-3, 2, n),
+          "drift_lin": rng.normal(0, 100, n), "drift_quad": rng.normal(0, 10, n)}
+    theta = np.stack([th[k] for k in free], axis=1)
+    logl = ref_loglike(table, free, fixed, theta)
+    np.savez_compressed(HERE / "loglike_wild.npz", theta=theta, logL=logl, parnames=np.array(free),
+                        insts=np.array(table.insts), fixed_names=np.array(list(fixed)),
+                        fixed_values=np.array(list(fixed.values()), dtype=float), **table_arrays("", table))
+    print(f"wild: {len(theta)} points, {int((logl == -1e30).sum())} invalid, finite logL in "
+          f"[{logl[logl > -1e29].min():.3e}, {logl.max():.3e}], non-finite {int((~np.isfinite(logl)).sum())}")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["configs", "edges", "51peg", "priors", "keprv", "high_ecc"]
+    which = sys.argv[1:] or ["configs", "edges", "51peg", "priors", "keprv", "high_ecc", "wild"]
+    if "wild" in which: gen_wild()
     if "high_ecc" in which: gen_high_ecc()
     if "configs" in which: gen_configs()
     if "edges" in which: gen_edges()
