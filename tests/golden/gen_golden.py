@@ -290,6 +290,15 @@ def gen_priors():
         ("Alpha", (1.5,)), ("Alpha", (3.0,)),
         ("Beta", (0.867, 3.03)), ("Beta", (2.0, 5.0)), ("Beta", (0.5, 0.5)), ("Beta", (12.0, 1.5)),
         ("Gamma", (2.0, 3.0)), ("Gamma", (0.7, 0.1)), ("Gamma", (25.0, 2.0)),
+        # round 2, second pass (appended): shape parameters far from anything a config would use
+        ("Beta", (0.05, 0.05)), ("Beta", (0.1, 20.0)), ("Beta", (30.0, 0.3)), ("Beta", (150.0, 300.0)), ("Beta", (1.0, 1.0)),
+        ("Beta", (1.0, 7.0)), ("Beta", (500.0, 2.0)), ("Beta", (0.3, 0.31)),
+        ("Gamma", (0.05, 1.0)), ("Gamma", (0.2, 5.0)), ("Gamma", (1.0, 0.5)), ("Gamma", (100.0, 0.01)), ("Gamma", (1000.0, 3.0)),
+        ("Gamma", (5.5, 1e3)),
+        ("Alpha", (0.3,)), ("Alpha", (10.0,)),
+        ("Normal", (1e6, 1e-3)), ("LogNormal", (3.0,)), ("LogNormal", (0.05, 2.0, 0.1)),
+        ("TruncatedRayleigh", (10.0, 1.0)), ("Jeffreys", (1e-8, 1e8)), ("ModJeffreys", (1e-3, 1e6)),
+        ("UniformFrequency", (0.01, 1e5)),
     ]
     arrays, meta = {"q": q}, []
     for i, (name, args) in enumerate(sets):

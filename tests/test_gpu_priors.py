@@ -25,7 +25,7 @@ def test_device_ppf_matches_reference(gpu_required, name, args, vals, raised):
         got = m.prior_transform_batch(Q.reshape(-1, 1))[:, 0]
     mask = pc.comparable_mask(name, Q, raised)
     err = pc.rel_err(got[mask], vals[mask], pc.abs_scale(name, args))
-    assert err.max() <= pc.TOL.get(name, pc.DEFAULT_TOL), (name, args, float(err.max()), float(Q[mask][err.argmax()]))
+    assert err.max() <= pc.base_tol(name, args), (name, args, float(err.max()), float(Q[mask][err.argmax()]))
     assert np.all(np.isnan(got[raised]))            # where the reference raises ValueError we return NaN
 
 

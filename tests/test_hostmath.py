@@ -54,7 +54,7 @@ def test_special_function_priors_match_golden(hm):
         seen.add(name)
         m = pc.comparable_mask(name, q, raised)
         err = pc.rel_err(got[m], vals[m])
-        assert err.max() <= pc.TOL.get(name, pc.DEFAULT_TOL), (name, args, float(err.max()), float(q[m][err.argmax()]))
+        assert err.max() <= pc.base_tol(name, args), (name, args, float(err.max()), float(q[m][err.argmax()]))
     assert seen == {"Beta", "Gamma", "Alpha", "Normal"}
 
 
