@@ -1,5 +1,7 @@
 """GPU parity: the device prior transform (rvll_prior_batch) against the golden vectors produced by the
 reference's own `.ppf` for every distribution of evidence/priors.py, plus the fused prior+log-L call."""
+import zlib
+
 import numpy as np
 import pytest
 
@@ -137,7 +139,7 @@ def test_device_ppf_matches_oracle_on_dense_random_q(gpu_required, name, args, v
     """Beyond the 64-point golden grid: 30 000 random unit-cube coordinates per distribution against the
     numpy/scipy oracle (itself pinned by the golden vectors, tests/test_priors_oracle.py)."""
     from oracle import priors_oracle as po
-    rng = np.random.default_rng(hash(name) % 1000)
+    rng = np.random.default_rng(zlib.crc32(f"{name}{tuple(args)}".encode()) % 100000)    # (str hashes change per process)
     q = np.concatenate([rng.random(28_000), 10.0 ** rng.uniform(-9, -1, 1000), 1 - 10.0 ** rng.uniform(-9, -1, 1000)])
     with one_param_model(pc.spec_for(name, args)) as m:
         got = m.prior_transform_batch(q.reshape(-1, 1))[:, 0]
