@@ -14,7 +14,7 @@ ap.add_argument("--seconds", type=float, default=60.0)
 args = ap.parse_args()
 rng = np.random.default_rng(123)
 t_end = time.time() + args.seconds
-walks = calls = scalars = 0
+walks = calls = scalars = bigs = 0
 models = {}
 for cfg in (1, 2, 3, 5):
     w = make_workload(cfg)
@@ -24,9 +24,14 @@ while time.time() < t_end:
     cfg = int(rng.choice([1, 2, 3, 3, 3, 5]))
     w, m = models[cfg]
     k = int(rng.integers(1, 6000 if cfg != 5 else 600))
+    big = cfg != 5 and rng.random() < 0.12                   # more rows than walker slots: the row queue and the two-part
+    if big:                                                  # launch come into play
+        k = int(rng.integers(12000, 40000))
+        bigs += 1
+    m.set_walk_speculation(int(rng.choice([1, 2, 4, 4, 8])))
     cube = rng.random((2 * k, m.ndim))
     theta, logl = m.prior_loglike_batch(cube)
-    lstar = float(np.quantile(logl, rng.uniform(0.3, 0.98)))
+    lstar = float(np.quantile(logl, rng.uniform(0.3, 0.6 if big else 0.98)))
     keep = logl > lstar
     if keep.sum() < 2:
         continue
@@ -50,4 +55,5 @@ while time.time() < t_end:
         print(f"... {walks} walks, {calls} likelihood calls, {scalars} scalar calls", flush=True)
 for w, m in models.values():
     m.close()
-print(f"soak ok: {walks} walks, {calls} likelihood calls inside walks, {scalars} scalar-server calls, all consistent")
+print(f"soak ok: {walks} walks ({bigs} of them with more rows than walker slots), {calls} likelihood calls inside walks, "
+      f"{scalars} scalar-server calls, all consistent")
