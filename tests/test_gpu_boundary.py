@@ -367,3 +367,33 @@ def test_scalar_server_answers_polychord_style_calls(gpu_required):
     # both handles were destroyed with their servers possibly still polling: a new model works at once
     with GpuRVModel(case.fixed, case.table, case.parnames) as m3:
         assert np.array_equal(m3.log_likelihood_batch(case.theta[:10]), want[:10])
+
+
+def test_every_transport_threshold_one_row_either_side(gpu_required):
+    """The three host-buffer entry points choose a transport by the size of the call (scalar server, zero-copy through
+    the mapped pinned blocks, pinned landing zone, overlapped chunks, staged downloads: csrc/rvll_api.hip).  Rows are
+    independent, so a call on any slice of one table returns the bits of those rows computed once through the
+    device-resident path — at every threshold, one row below and one above (scripts/host_call_soak.py soaks the same
+    with random sizes; profiles/r02_host_call_soak.txt)."""
+    nbig = 140_000
+    w = make_workload(3)
+    rng = np.random.default_rng(9)
+    cube = w.sample_cube(nbig, seed=43)
+    cube[::997] *= 1e-9                                                   # rows hard against the cube's walls
+    with GpuRVModel(w.fixedpardict, w.table, w.parnames, priordict=w.priordict()) as m:
+        D = m.ndim
+        m.dev_upload_cube(cube); m.dev_prior(nbig); m.dev_loglike(nbig)
+        theta, logl, flags = (a.copy() for a in m.dev_download(nbig, theta=True, flags=True))
+        sizes = {1, 2, 63, 64, 65, 4095, 4096, 4097, 16383, 16384, 16385, 65535, 65536, 65537, 131071, 131072, 131073, nbig}
+        for T in (64 << 10, 384 << 10, 1 << 20, 8 << 20):
+            for r in (8 * D, 16 * D, 12, 8 * D + 12, 16 * D + 12):
+                n = T // r
+                sizes.update(k for k in (n - 1, n, n + 1) if 1 <= k <= nbig)
+        for n in sorted(sizes):
+            o = int(rng.integers(0, nbig - n + 1))
+            got, fl = m.log_likelihood_batch(theta[o:o + n], return_flags=True)
+            assert np.array_equal(got, logl[o:o + n]) and np.array_equal(fl, flags[o:o + n]), ("loglike", n)
+            assert np.array_equal(m.prior_transform_batch(cube[o:o + n]), theta[o:o + n]), ("prior", n)
+            th, got, fl = m.prior_loglike_batch(cube[o:o + n], return_flags=True)
+            assert np.array_equal(th, theta[o:o + n]) and np.array_equal(got, logl[o:o + n]) and \
+                np.array_equal(fl, flags[o:o + n]), ("prior_loglike", n)
