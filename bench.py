@@ -301,8 +301,9 @@ def run_extras(out, model, w, theta, B, with_cpu):
 
     def prior_plus_loglike():             # cube -> theta -> log-L all on the device
         model.set_priors(w.priordict())
-        def timed(n, step, reps):
-            model.dev_fill_cube(n, seed=99)
+        def timed(n, step, reps, fill=True):
+            if fill:
+                model.dev_fill_cube(n, seed=99)
             for _ in range(5):
                 step()
             model.dev_sync()
@@ -314,6 +315,9 @@ def run_extras(out, model, w, theta, B, with_cpu):
         out["prior_plus_loglike_evals_per_s"] = timed(B, lambda: (model.dev_prior(B), model.dev_loglike(B)), 50)
         # the same in ONE launch: the slim prior stage in front of the CU-wide log-L tile (rvll_dev_prior_loglike)
         out["prior_plus_loglike_one_launch_evals_per_s"] = timed(B, lambda: model.dev_prior_loglike(B), 50)
+        # ... and the log-L kernel by itself on exactly those points (theta is resident from the call above): the
+        # headline batch is another draw, and a launch's time depends on which points it gets
+        out["loglike_alone_on_those_points_evals_per_s"] = timed(B, lambda: model.dev_loglike(B), 50, fill=False)
         # a sampler's proposal round: a small batch, where a launch is a large part of the step — the prior transform
         # in the log-L tile's staging step (one launch) against prior kernels + log-L kernel; a sync per step, as a
         # sampler that looks at every result would have

@@ -450,7 +450,8 @@ __device__ __forceinline__ TileLds tile_views(const LoglikeArgs& a, double* smem
 
 // 1. stage the tile's theta rows (one contiguous, coalesced span) + the layout structs + init.  Fused form: the rows
 //    are unit-cube coordinates and go through the prior transform on the way in (light kinds element by element,
-//    then the iterative kinds compacted so that consecutive lanes all run a solve); theta is written back.
+//    the iterative kinds compacted so that consecutive lanes all run a solve, in other waves); theta lands in LDS and
+//    is written back here (256-thread tiles) or by the caller after its barrier (CU-wide form, loglike_tile).
 template <int FUSED, int NT>
 __device__ __forceinline__ void tile_stage(const LoglikeArgs& __restrict__ a, const TileLds& L, long long p0, int npts,
                                            unsigned long long* stamp = nullptr, const double* cube_rows = nullptr)
@@ -463,17 +464,25 @@ __device__ __forceinline__ void tile_stage(const LoglikeArgs& __restrict__ a, co
     if constexpr (FUSED != kFusedNone) {
         // cube_rows: the tile's unit-cube rows where the caller already holds them (the walk: in LDS), else a.cube
         const double* src = cube_rows ? cube_rows : a.cube + p0 * a.D;
-        double* dst = a.theta_out + p0 * a.D;
+        // theta_out: the CU-wide form writes it from LDS in whole rows after the caller's barrier (loglike_tile); the
+        // 256-thread tiles write it element by element here (a second pass over a small tile costs them more than the
+        // lone stores); a caller that holds the rows in LDS (the walk) reads theta from LDS too and gets no copy
+        double* dst = (NT != kCuThreads && !cube_rows) ? a.theta_out + p0 * a.D : nullptr;
+        // Lanes run over the tile's elements POINT-fastest: the 64 lanes of a wave then work on one parameter — one
+        // prior kind, one path through the switch — wherever the tile has 64 points (the CU-wide form), on 64 / npts
+        // parameters otherwise; parameter-fastest, every wave ran every kind of the model one after the other.  The
+        // iterative kinds are dealt from the BACK of the workgroup, so that they run in other waves than the tail of
+        // the light ones instead of behind it.  (Same function per element either way: same bits.)
         for (int i = tid; i < npts * a.D; i += NT) {
-            const int pl = i / a.D, d = i - pl * a.D;
+            const int d = i / npts, pl = i - d * npts;
             if (prior_is_heavy(a.priors[d].kind)) continue;
             const double v = prior_light(a.priors, a.D, src + pl * a.D, d);
-            L.theta_s[i] = v;
-            dst[i] = v;
+            L.theta_s[pl * a.D + d] = v;
+            if (dst) dst[pl * a.D + d] = v;
         }
-        for (int i = tid; i < npts * a.n_heavy; i += NT) {
-            const int pl = i / a.n_heavy;
-            const int d = a.heavy_dims[i - pl * a.n_heavy];
+        for (int i = NT - 1 - tid; i < npts * a.n_heavy; i += NT) {
+            const int k = i / npts, pl = i - k * npts;
+            const int d = a.heavy_dims[k];
             double v;
             if constexpr (FUSED == kFusedSlim) {
                 bool deferred = false;
@@ -486,7 +495,7 @@ __device__ __forceinline__ void tile_stage(const LoglikeArgs& __restrict__ a, co
                 v = prior_heavy(a.priors[d], src[pl * a.D + d]);
             }
             L.theta_s[pl * a.D + d] = v;
-            dst[pl * a.D + d] = v;
+            if (dst) dst[pl * a.D + d] = v;
         }
     } else {
         const double* src = cube_rows ? cube_rows : a.theta + p0 * a.D;       // (the theta form's rows, likewise)
@@ -671,6 +680,14 @@ __device__ __forceinline__ __attribute__((flatten)) void loglike_tile(const Logl
     if constexpr (!DYN) __builtin_amdgcn_s_setprio(3);
     tile_stage<FUSED, NT>(a, L, p0, npts, TRACE && DYN ? tr + 1 : nullptr, cube_rows);
     __syncthreads();
+    if constexpr (FUSED != kFusedNone && NT == kCuThreads) {
+        // theta goes out from LDS in whole rows (the stage's lanes run point-fastest: written there, every store would
+        // have been a lone 8 bytes of its cache line); the stores drain under the decode step and the item loop
+        if (!cube_rows) {
+            double* dst = a.theta_out + p0 * a.D;
+            for (int i = tid; i < npts * a.D; i += NT) dst[i] = L.theta_s[i];
+        }
+    }
     if constexpr (TRACE && DYN) { if (tid == 0) tr[2] = __builtin_amdgcn_s_memrealtime(); }
     tile_decode<NT>(a, L, npts);
     __syncthreads();
