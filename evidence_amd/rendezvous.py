@@ -1,4 +1,4 @@
-"""A ~100-line control plane for one-process-per-GPU runs: no torch, no MPI.
+"""A small control plane for one-process-per-GPU runs: no torch, no MPI, no pickle.
 
 The reference leaves process management to MPI inside its third-party samplers
 (evidence/polychord/__init__.py:21-29,176-199; evidence/ultranest/__init__.py:21-29,151-194).  Here the data
@@ -8,7 +8,7 @@ path between GPUs is RCCL (rvll_allgather_*); what the ranks need besides is tin
 rank 0 in the middle:
 
     Rendezvous.from_env()         RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT as the launcher exports them
-    .broadcast(obj, src=0)        picklable object from rank src to every rank
+    .broadcast(obj, src=0)        object from rank src to every rank
     .allgather(obj)               list of every rank's object, in rank order, on every rank
     .barrier()
     .allreduce(x, op)             op in {"max", "min", "sum"} over python numbers
@@ -18,32 +18,220 @@ MASTER_ADDR, MASTER_PORT and the launcher's run id — `python -m torch.distribu
 LISTENING on MASTER_PORT, so on the one node it launches for, the ranks meet beside it, not on it.
 Importing this module must not import torch: with torch loaded first a process binds torch's bundled HIP
 runtime and RCCL instead of the ROCm ones librvll.so is built against.
+
+What travels (round 3; ADVICE r2: the first version unpickled whatever arrived, from whoever connected):
+  * a closed set of VALUES — None, bool, int, float, str, bytes, numpy arrays of plain numeric dtypes, and lists /
+    tuples / dicts of those — in a tagged binary encoding (`encode` / `decode` below).  Decoding allocates buffers
+    and nothing else: there is no object construction a peer could steer;
+  * every frame carries an HMAC-SHA256 over (direction, sender's frame counter, payload) under a key both ends
+    derive from a shared secret: RVLL_RDZV_SECRET if set (bench.py's own launcher draws 32 random bytes per run and
+    hands them to its children through the environment), else the run id the launcher exports.  A frame that does
+    not verify closes the connection before a single payload byte is decoded; a replayed or reordered frame does not
+    verify either (the counter is part of the MAC);
+  * the join is a challenge / response: rank 0 sends a fresh nonce, the peer answers with its rank and
+    HMAC(key, nonce | rank), as a fixed-size struct;
+  * on unix sockets rank 0 also drops peers of another uid (SO_PEERCRED) before reading anything.
 """
+import hashlib
+import hmac
 import os
-import pickle
 import socket
 import struct
 import time
+
+import numpy as np
 
 
 class RendezvousError(RuntimeError):
     pass
 
 
-def _send(sock, obj):
-    data = pickle.dumps(obj, protocol=pickle.HIGHEST_PROTOCOL)
-    sock.sendall(struct.pack("!Q", len(data)) + data)
+class RendezvousTimeout(RendezvousError):
+    """A peer did not send within the rendezvous' timeout."""
 
 
-def _recv(sock):
-    head = _recv_exact(sock, 8)
-    return pickle.loads(_recv_exact(sock, struct.unpack("!Q", head)[0]))
+# ---- values on the wire -------------------------------------------------------------------------------------------
+_MAX_FRAME = 1 << 31                 # bytes; a length beyond this is a protocol error, not an allocation
+_MAX_DEPTH = 16
+_DTYPES = ("f8", "f4", "i8", "i4", "i2", "i1", "u8", "u4", "u2", "u1", "b1")
+
+
+def _enc(obj, out, depth=0):
+    if depth > _MAX_DEPTH:
+        raise RendezvousError("value nested too deeply for the rendezvous")
+    if obj is None:
+        out.append(b"N")
+    elif isinstance(obj, (bool, np.bool_)):
+        out.append(b"T" if obj else b"F")
+    elif isinstance(obj, (int, np.integer)):
+        v = int(obj)
+        if -(1 << 63) <= v < (1 << 63):
+            out.append(b"i" + struct.pack("!q", v))
+        else:
+            s = str(v).encode()
+            out.append(b"I" + struct.pack("!I", len(s)) + s)
+    elif isinstance(obj, (float, np.floating)):
+        out.append(b"d" + struct.pack("!d", float(obj)))
+    elif isinstance(obj, str):
+        s = obj.encode("utf-8")
+        out.append(b"s" + struct.pack("!Q", len(s)) + s)
+    elif isinstance(obj, (bytes, bytearray, memoryview)):
+        b = bytes(obj)
+        out.append(b"b" + struct.pack("!Q", len(b)) + b)
+    elif isinstance(obj, np.ndarray):
+        code = obj.dtype.str.lstrip("<>=|")
+        if code not in _DTYPES or obj.dtype.byteorder == ">":
+            raise RendezvousError(f"the rendezvous does not carry arrays of dtype {obj.dtype}")
+        a = np.ascontiguousarray(obj)
+        out.append(b"a" + struct.pack("!BB", _DTYPES.index(code), a.ndim) + struct.pack(f"!{a.ndim}Q", *a.shape))
+        out.append(a.tobytes())
+    elif isinstance(obj, (list, tuple)):
+        out.append((b"l" if isinstance(obj, list) else b"t") + struct.pack("!Q", len(obj)))
+        for item in obj:
+            _enc(item, out, depth + 1)
+    elif isinstance(obj, dict):
+        out.append(b"m" + struct.pack("!Q", len(obj)))
+        for k, v in obj.items():
+            _enc(k, out, depth + 1)
+            _enc(v, out, depth + 1)
+    else:
+        raise RendezvousError(f"the rendezvous does not carry values of type {type(obj).__name__}")
+
+
+def encode(obj) -> bytes:
+    out = []
+    _enc(obj, out)
+    return b"".join(out)
+
+
+class _Reader:
+    def __init__(self, data):
+        self.data, self.pos = memoryview(data), 0
+
+    def take(self, n):
+        if n < 0 or self.pos + n > len(self.data):
+            raise RendezvousError("truncated rendezvous frame")
+        v = self.data[self.pos:self.pos + n]
+        self.pos += n
+        return v
+
+    def unpack(self, fmt):
+        return struct.unpack(fmt, self.take(struct.calcsize(fmt)))
+
+
+def _dec(r, depth=0):
+    if depth > _MAX_DEPTH:
+        raise RendezvousError("value nested too deeply for the rendezvous")
+    tag = bytes(r.take(1))
+    if tag == b"N":
+        return None
+    if tag in (b"T", b"F"):
+        return tag == b"T"
+    if tag == b"i":
+        return r.unpack("!q")[0]
+    if tag == b"I":
+        return int(bytes(r.take(r.unpack("!I")[0])).decode("ascii"))
+    if tag == b"d":
+        return r.unpack("!d")[0]
+    if tag == b"s":
+        return bytes(r.take(r.unpack("!Q")[0])).decode("utf-8")
+    if tag == b"b":
+        return bytes(r.take(r.unpack("!Q")[0]))
+    if tag == b"a":
+        code, ndim = r.unpack("!BB")
+        if code >= len(_DTYPES) or ndim > 8:
+            raise RendezvousError("malformed array header in a rendezvous frame")
+        shape = r.unpack(f"!{ndim}Q")
+        dt = np.dtype(_DTYPES[code])
+        count = 1
+        for s in shape:
+            count *= s
+        if count * dt.itemsize > len(r.data) - r.pos:            # before any allocation
+            raise RendezvousError("truncated rendezvous frame")
+        return np.frombuffer(r.take(count * dt.itemsize), dtype=dt).reshape(shape).copy()
+    if tag in (b"l", b"t"):
+        n = r.unpack("!Q")[0]
+        if n > len(r.data) - r.pos:                              # every item takes at least its tag byte
+            raise RendezvousError("truncated rendezvous frame")
+        items = [_dec(r, depth + 1) for _ in range(n)]
+        return items if tag == b"l" else tuple(items)
+    if tag == b"m":
+        n = r.unpack("!Q")[0]
+        if 2 * n > len(r.data) - r.pos:
+            raise RendezvousError("truncated rendezvous frame")
+        out = {}
+        for _ in range(n):
+            k = _dec(r, depth + 1)
+            out[k] = _dec(r, depth + 1)
+        return out
+    raise RendezvousError(f"unknown tag {tag!r} in a rendezvous frame")
+
+
+def decode(data):
+    r = _Reader(data)
+    v = _dec(r)
+    if r.pos != len(r.data):
+        raise RendezvousError("trailing bytes in a rendezvous frame")
+    return v
+
+
+# ---- authenticated frames ---------------------------------------------------------------------------------------------
+def shared_key(address, env=os.environ) -> bytes:
+    """Key of the frame MACs: derived from RVLL_RDZV_SECRET (hex or text; bench.py's launcher draws one per run), else
+    from the launcher's run id — known to the ranks of one job, not to a stranger who merely finds the socket."""
+    secret = env.get("RVLL_RDZV_SECRET") or "|".join(
+        env.get(k, "") for k in ("TORCHELASTIC_RUN_ID", "MASTER_ADDR", "MASTER_PORT"))
+    return hashlib.sha256(b"rvll-rdzv-v2|" + secret.encode() + b"|" + address.encode()).digest()
+
+
+class _Channel:
+    """One stream socket with counted, MAC-ed frames: [len u64][mac 32][payload]."""
+
+    def __init__(self, sock, key, me, peer):
+        self.sock, self.key = sock, key
+        self.tx_tag, self.rx_tag = struct.pack("!II", me, peer), struct.pack("!II", peer, me)
+        self.tx = self.rx = 0
+
+    def _mac(self, tag, counter, payload):
+        return hmac.new(self.key, tag + struct.pack("!Q", counter) + payload, hashlib.sha256).digest()
+
+    def send(self, obj):
+        payload = encode(obj)
+        try:
+            self.sock.sendall(struct.pack("!Q", len(payload)) + self._mac(self.tx_tag, self.tx, payload) + payload)
+        except socket.timeout as exc:
+            raise RendezvousTimeout("the peer did not take data within the rendezvous timeout") from exc
+        except OSError as exc:
+            raise RendezvousError(f"peer closed the connection ({exc})") from exc
+        self.tx += 1
+
+    def recv(self):
+        head = _recv_exact(self.sock, 40)
+        n = struct.unpack("!Q", head[:8])[0]
+        if n > _MAX_FRAME:
+            raise RendezvousError("rendezvous frame length out of range")
+        payload = _recv_exact(self.sock, n)
+        if not hmac.compare_digest(head[8:], self._mac(self.rx_tag, self.rx, payload)):
+            raise RendezvousError("rendezvous frame failed authentication")
+        self.rx += 1
+        return decode(payload)
+
+    def close(self):
+        try:
+            self.sock.close()
+        except OSError:
+            pass
 
 
 def _recv_exact(sock, n):
     buf = bytearray()
     while len(buf) < n:
-        chunk = sock.recv(min(1 << 20, n - len(buf)))
+        try:
+            chunk = sock.recv(min(1 << 20, n - len(buf)))
+        except socket.timeout as exc:
+            raise RendezvousTimeout("no data from the peer within the rendezvous timeout") from exc
+        except OSError as exc:                             # reset, broken pipe, closed under us
+            raise RendezvousError(f"peer closed the connection ({exc})") from exc
         if not chunk:
             raise RendezvousError("peer closed the connection")
         buf += chunk
@@ -75,28 +263,41 @@ def _open(address, listen):
     return s, target
 
 
+def _same_user(conn):
+    """unix sockets: the connecting process runs under this process's uid (SO_PEERCRED: pid, uid, gid)."""
+    try:
+        cred = conn.getsockopt(socket.SOL_SOCKET, socket.SO_PEERCRED, struct.calcsize("3i"))
+        return struct.unpack("3i", cred)[1] == os.getuid()
+    except (OSError, AttributeError):
+        return True                                        # not available on this platform: the MAC still stands
+
+
+_HELLO = struct.Struct("!4sI32s")                          # magic, rank, HMAC(key, nonce | rank)
+
+
 class Rendezvous:
-    def __init__(self, rank, world, address=None, timeout=120.0):
+    def __init__(self, rank, world, address=None, timeout=120.0, key=None):
         if not 0 <= rank < world:
             raise ValueError("0 <= rank < world required")
         self.rank, self.world, self.timeout = rank, world, timeout
         self.address = address or default_address()
-        self._peers = {}                                   # rank 0: rank -> socket
-        self._hub = None                                   # other ranks: socket to rank 0
+        self.key = key if key is not None else shared_key(self.address)
+        self._peers = {}                                   # rank 0: rank -> channel
+        self._hub = None                                   # other ranks: channel to rank 0
         if world == 1:
             return
         if rank == 0:
             srv, _ = _open(self.address, listen=True)
-            srv.settimeout(timeout)
+            deadline = time.monotonic() + timeout
             try:
                 while len(self._peers) < world - 1:
+                    srv.settimeout(max(0.05, deadline - time.monotonic()))
                     conn, _ = srv.accept()
-                    conn.settimeout(timeout)
-                    peer = _recv(conn)
-                    if not isinstance(peer, int) or not 0 < peer < world or peer in self._peers:
+                    peer = self._admit(conn)
+                    if peer is None:                       # a stranger (wrong uid, wrong key, nonsense): dropped, keep waiting
                         conn.close()
-                        raise RendezvousError(f"unexpected peer announcement {peer!r}")
-                    self._peers[peer] = conn
+                        continue
+                    self._peers[peer] = _Channel(conn, self.key, 0, peer)
             except socket.timeout as exc:
                 raise RendezvousError(f"only {len(self._peers) + 1} of {world} ranks arrived at {self.address}") from exc
             finally:
@@ -114,8 +315,32 @@ class Rendezvous:
                         raise RendezvousError(f"rank 0 is not listening at {self.address}")
                     time.sleep(0.05)
             s.settimeout(timeout)
-            _send(s, rank)
-            self._hub = s
+            nonce = _recv_exact(s, 32)
+            proof = hmac.new(self.key, nonce + struct.pack("!I", rank), hashlib.sha256).digest()
+            try:
+                s.sendall(_HELLO.pack(b"RVL2", rank, proof))
+            except OSError as exc:
+                raise RendezvousError(f"rank 0 closed the connection during the join ({exc})") from exc
+            self._hub = _Channel(s, self.key, rank, 0)
+
+    def _admit(self, conn):
+        """Rank 0's side of the join: uid check (unix), nonce out, fixed-size answer back.  Returns the rank or None."""
+        try:
+            if self.address.startswith("unix:") and not _same_user(conn):
+                return None
+            conn.settimeout(min(self.timeout, 10.0))
+            nonce = os.urandom(32)
+            conn.sendall(nonce)
+            magic, peer, proof = _HELLO.unpack(_recv_exact(conn, _HELLO.size))
+            want = hmac.new(self.key, nonce + struct.pack("!I", peer), hashlib.sha256).digest()
+            if magic != b"RVL2" or not hmac.compare_digest(proof, want):
+                return None
+            if not 0 < peer < self.world or peer in self._peers:
+                return None
+            conn.settimeout(self.timeout)
+            return peer
+        except (RendezvousError, OSError, struct.error):
+            return None
 
     @classmethod
     def from_env(cls, env=os.environ, **kw):
@@ -126,13 +351,13 @@ class Rendezvous:
             return [obj]
         if self.rank == 0:
             items = [obj] + [None] * (self.world - 1)
-            for r, s in self._peers.items():
-                items[r] = _recv(s)
-            for s in self._peers.values():
-                _send(s, items)
+            for r, ch in self._peers.items():
+                items[r] = ch.recv()
+            for ch in self._peers.values():
+                ch.send(items)
             return items
-        _send(self._hub, obj)
-        return _recv(self._hub)
+        self._hub.send(obj)
+        return self._hub.recv()
 
     def broadcast(self, obj, src=0):
         return self.allgather(obj if self.rank == src else None)[src]
@@ -145,11 +370,8 @@ class Rendezvous:
         return {"max": max, "min": min, "sum": sum}[op](vals)
 
     def close(self):
-        for s in list(self._peers.values()) + ([self._hub] if self._hub else []):
-            try:
-                s.close()
-            except OSError:
-                pass
+        for ch in list(self._peers.values()) + ([self._hub] if self._hub else []):
+            ch.close()
         self._peers, self._hub = {}, None
 
     def __enter__(self):

@@ -7,10 +7,13 @@ produced on the device from a cube shard (ShardedPriorLogLike), its rows travel 
 
 Three transports for the same partition:
   "rccl"  the device buffer the log-L kernel wrote is all-gathered in place by RCCL over xGMI on the
-          handle's stream (rvll_allgather_logl; host-side rows: rvll_allgather_host) — the product path on a GPU node;
+          handle's stream (rvll_allgather_logl; host-side rows: rvll_allgather_host) — the product path on a GPU node,
+          and the DEFAULT whenever a model is passed;
   "rdzv"  host buffers over evidence_amd/rendezvous.py (plain sockets, no torch) — the fallback transport if RCCL
-          cannot be initialised, and what a launcher-less script can use;
-  "dist"  torch.distributed all_gather of host buffers (gloo) — used by the CPU tests of the sharding logic.
+          cannot be initialised, what a launcher-less script can use, and the default when only group= is passed;
+  "dist"  torch.distributed all_gather of host buffers (gloo) — opt-in (transport="dist"): the CPU tests of the
+          sharding logic use it.  It is never chosen by default: importing torch before the first HIP call binds
+          torch's bundled HIP runtime and RCCL instead of the ROCm ones librvll.so is built against.
 The evaluation itself is always whatever `evaluate` is: GpuRVModel.log_likelihood_batch in the product.
 """
 from typing import Callable, List, Tuple
@@ -51,12 +54,22 @@ def gather_rows(mine: np.ndarray, world: int, transport: str, model=None, group=
 
 
 def _check_transport(transport, model, group):
+    """-> the transport to use.  None picks the product default: "rccl" through the model's communicator when a model
+    is given, else "rdzv" over the given rendezvous; torch ("dist") only ever on request."""
+    if transport is None:
+        if group is not None and model is None:
+            transport = "rdzv"
+        elif model is not None:
+            transport = "rccl"
+        else:
+            raise ValueError('pass model= (RCCL, the default), group= (rendezvous sockets) or transport="dist" (torch / gloo, opt-in)')
     if transport not in ("dist", "rccl", "rdzv"):
         raise ValueError(transport)
     if transport == "rccl" and model is None:
         raise ValueError("the rccl transport gathers through the model's communicator: pass model=")
     if transport == "rdzv" and group is None:
         raise ValueError("the rdzv transport needs group= (an evidence_amd.rendezvous.Rendezvous)")
+    return transport
 
 
 def unpad(gathered: np.ndarray, n_points: int, world: int) -> np.ndarray:
@@ -72,8 +85,8 @@ class ShardedLogLike:
     one all-gather.  Returns the full [n] log-L vector on every rank."""
 
     def __init__(self, rank: int, world: int, evaluate: Callable[[np.ndarray], np.ndarray] = None,
-                 model=None, transport: str = "dist", group=None):
-        _check_transport(transport, model, group)
+                 model=None, transport: str = None, group=None):
+        transport = _check_transport(transport, model, group)
         if evaluate is None and model is None:
             raise ValueError("pass evaluate= or model=")
         self.rank, self.world, self.model, self.transport, self.group = rank, world, model, transport, group
@@ -110,9 +123,9 @@ class ShardedPriorLogLike:
     Returns (theta [n, ndim], logL [n]) on every rank.  Transports as in ShardedLogLike; with "dist" the
     evaluation is `evaluate(cubes) -> (theta, logL)` (GpuRVModel.prior_loglike_batch in the product)."""
 
-    def __init__(self, rank: int, world: int, evaluate: Callable = None, model=None, transport: str = "dist",
+    def __init__(self, rank: int, world: int, evaluate: Callable = None, model=None, transport: str = None,
                  group=None):
-        _check_transport(transport, model, group)
+        transport = _check_transport(transport, model, group)
         if evaluate is None and model is None:
             raise ValueError("pass evaluate= or model=")
         self.rank, self.world, self.model, self.transport, self.group = rank, world, model, transport, group
@@ -161,8 +174,8 @@ class ShardedWalker:
     GpuRVModel.slice_walk in the product.  Transports as in ShardedLogLike ("rccl": model=, through
     rvll_allgather_host)."""
 
-    def __init__(self, rank: int, world: int, walk: Callable, transport: str = "dist", model=None, group=None):
-        _check_transport(transport, model, group)
+    def __init__(self, rank: int, world: int, walk: Callable, transport: str = None, model=None, group=None):
+        transport = _check_transport(transport, model, group)
         self.rank, self.world, self.walk = rank, world, walk
         self.transport, self.model, self.group = transport, model, group
 

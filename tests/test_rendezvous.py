@@ -2,6 +2,7 @@
 and 3 — the exchange bench.py and the sharded samplers use beside RCCL: id broadcast, barrier, max / min over ranks,
 all-gather of small host buffers — and the socket transport of the sharded log-L."""
 import multiprocessing as mp
+import time
 import os
 import subprocess
 import sys
@@ -91,3 +92,96 @@ def test_the_control_plane_and_the_bench_launch_path_do_not_import_torch():
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     assert out.stdout.strip() == "False"
+
+
+def test_wire_format_carries_a_closed_set_of_values_and_nothing_else():
+    """the first version unpickled whatever arrived.  The codec now carries plain values only; decoding
+    never constructs anything but numbers, strings, bytes, arrays and containers of those."""
+    from evidence_amd.rendezvous import RendezvousError, decode, encode
+    value = {"rank": 3, "x": np.arange(6, dtype=np.float64).reshape(2, 3), "id": bytes(range(128)), "ok": True,
+             "none": None, "big": 2 ** 80, "t": (1.5, "s", [np.int32(7), np.float32(0.25)]),
+             "flags": np.array([1, 0, 2], dtype=np.int32), "empty": np.empty((0, 4))}
+    back = decode(encode(value))
+    assert back["rank"] == 3 and back["id"] == bytes(range(128)) and back["ok"] is True and back["none"] is None
+    assert back["big"] == 2 ** 80 and back["t"] == (1.5, "s", [7, 0.25])
+    assert np.array_equal(back["x"], value["x"]) and back["x"].dtype == np.float64 and back["x"].flags.writeable
+    assert np.array_equal(back["flags"], value["flags"]) and back["flags"].dtype == np.int32
+    assert back["empty"].shape == (0, 4)
+    for bad in (object(), {1, 2}, np.array(["a"]), np.array([1 + 2j]), lambda: 0):
+        with pytest.raises(RendezvousError):
+            encode(bad)
+    import pickle
+    for junk in (pickle.dumps({"a": 1}), b"", b"a\xff\x01", encode([1, 2]) + b"x", b"l" + (2 ** 40).to_bytes(8, "big"),
+                 b"a\x00\x01" + (2 ** 50).to_bytes(8, "big")):
+        with pytest.raises(RendezvousError):
+            decode(junk)
+
+
+def _auth_worker(rank, address, key, q):
+    sys.path.insert(0, str(REPO))
+    from evidence_amd.rendezvous import Rendezvous, RendezvousError
+    try:
+        with Rendezvous(rank, 2, address=address, timeout=6, key=key) as rz:
+            q.put((rank, rz.allreduce(rank + 1, "sum")))
+    except RendezvousError as exc:
+        q.put((rank, f"error: {exc}"))
+
+
+def test_a_peer_without_the_key_is_not_admitted_and_a_tampered_frame_is_refused():
+    import socket
+    import struct
+    from evidence_amd.rendezvous import Rendezvous, RendezvousError, _Channel, _recv_exact, encode
+    ctx = mp.get_context("spawn")
+    # 1. a rank with another key never joins: rank 0 keeps waiting and reports who is missing; the stranger sees the
+    #    connection dropped
+    q = ctx.Queue()
+    address = f"unix:rvll-auth-{os.getpid()}"
+    procs = [ctx.Process(target=_auth_worker, args=(0, address, b"k" * 32, q)),
+             ctx.Process(target=_auth_worker, args=(1, address, b"x" * 32, q))]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=60) for _ in range(2))
+    for p in procs:
+        p.join(timeout=30)
+    assert "only 1 of 2 ranks arrived" in got[0] and str(got[1]).startswith("error")
+    # 2. a pickle (what the first version would have unpickled) sent instead of the fixed-size hello is dropped, and the
+    #    genuine rank that connects afterwards is admitted
+    address = f"unix:rvll-auth2-{os.getpid()}"
+    p0 = ctx.Process(target=_auth_worker, args=(0, address, b"k" * 32, q))
+    p0.start()
+    import pickle
+    deadline = time.monotonic() + 30
+    while True:
+        s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        try:
+            s.connect("\0" + address.partition(":")[2])
+            break
+        except OSError:
+            s.close()
+            assert time.monotonic() < deadline
+            time.sleep(0.05)
+    data = pickle.dumps(1)
+    s.sendall(struct.pack("!Q", len(data)) + data + b"\0" * 64)
+    p1 = ctx.Process(target=_auth_worker, args=(1, address, b"k" * 32, q))
+    p1.start()
+    got = dict(q.get(timeout=60) for _ in range(2))
+    s.close()
+    for p in (p0, p1):
+        p.join(timeout=30)
+    assert got == {0: 3, 1: 3}
+    # 3. frames: a flipped payload bit, a replayed frame and a frame from the wrong direction all fail the MAC
+    a, b = socket.socketpair()
+    tx, rx = _Channel(a, b"k" * 32, 1, 0), _Channel(b, b"k" * 32, 0, 1)
+    tx.send({"v": np.arange(4.0)})
+    assert np.array_equal(rx.recv()["v"], np.arange(4.0))
+    payload = encode([1, 2, 3])
+    frame = struct.pack("!Q", len(payload)) + tx._mac(tx.tx_tag, tx.tx, payload) + payload
+    a.sendall(frame[:-1] + bytes([frame[-1] ^ 1]))
+    with pytest.raises(RendezvousError, match="authentication"):
+        rx.recv()
+    a.sendall(frame)                                   # the genuine frame: accepted once ...
+    assert rx.recv() == [1, 2, 3]
+    a.sendall(frame)                                   # ... and refused when replayed (the counter moved on)
+    with pytest.raises(RendezvousError, match="authentication"):
+        rx.recv()
+    a.close(); b.close()

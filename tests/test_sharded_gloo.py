@@ -132,7 +132,7 @@ def _walk_worker(rank, world, port, n, q):
         def walk(*a, **kw):
             calls.append((len(a[0]), kw.get("walker_base")))
             return _fake_walk(*a, **kw)
-        out = ShardedWalker(rank, world, walk)(cube, 10.0 * cube - 3.0, logl, -1.0, np.eye(4), None, 5, 200, 17)
+        out = ShardedWalker(rank, world, walk, transport="dist")(cube, 10.0 * cube - 3.0, logl, -1.0, np.eye(4), None, 5, 200, 17)
         q.put((rank, out, calls))
     finally:
         dist.destroy_process_group()
@@ -176,3 +176,37 @@ def test_shard_random_streams_do_not_overlap():
     a = _fake_walk(np.zeros((5, 2)), None, np.zeros(5), 0, 0, 0, 0, 0, 9, walker_base=0)[0]
     b = _fake_walk(np.zeros((5, 2)), None, np.zeros(5), 0, 0, 0, 0, 0, 9, walker_base=5)[0]
     assert not np.intersect1d(a[:, 0], b[:, 0]).size  # different rows, different draws
+
+
+def test_default_transport_is_rccl_or_the_rendezvous_never_torch():
+    """the sharded wrappers defaulted to transport="dist", which imports torch — and a process that
+    imports torch before its first HIP call binds torch's bundled HIP runtime and RCCL.  The product default is RCCL
+    through the model's communicator (or the rendezvous sockets when only a group is given); gloo is opt-in."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    repo = Path(__file__).resolve().parents[1]
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from evidence_amd.sharded import ShardedLogLike, ShardedPriorLogLike, ShardedWalker\n"
+        "from evidence_amd.rendezvous import Rendezvous\n"
+        "class M:\n"
+        "    def log_likelihood_batch(self, x): return -(x ** 2).sum(axis=1)\n"
+        "    def prior_loglike_batch(self, c): return c, -(c ** 2).sum(axis=1)\n"
+        "    def slice_walk(self, *a, **k): raise AssertionError\n"
+        "m, rz = M(), Rendezvous(0, 1)\n"
+        "assert ShardedLogLike(0, 1, model=m).transport == 'rccl'\n"
+        "assert ShardedPriorLogLike(0, 1, model=m).transport == 'rccl'\n"
+        "assert ShardedWalker(0, 1, m.slice_walk, model=m).transport == 'rccl'\n"
+        "s = ShardedLogLike(0, 1, evaluate=m.log_likelihood_batch, group=rz)\n"
+        "assert s.transport == 'rdzv' and s(np.ones((5, 2))).shape == (5,)\n"
+        "assert ShardedWalker(0, 1, m.slice_walk, group=rz).transport == 'rdzv'\n"
+        "for make in (lambda: ShardedLogLike(0, 1, evaluate=m.log_likelihood_batch), lambda: ShardedWalker(0, 1, m.slice_walk)):\n"
+        "    try: make()\n"
+        "    except ValueError as e: assert 'opt-in' in str(e)\n"
+        "    else: raise AssertionError('no transport chosen silently')\n"
+        "print('torch' in sys.modules)\n") % str(repo)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip() == "False"
