@@ -18,6 +18,8 @@ ERROR_NAMES = {
 
 FLAG_INVALID_ORBIT = 1
 FLAG_NONCONVERGED = 2
+FLAG_WANDERED = 4                  # a Kepler solve took > 8 Newton steps: log-L there is conditioned to ~1e-9 (rvll.h)
+ABI_VERSION = (0, 2)               # RVLL_VERSION_MAJOR / MINOR these bindings were written against
 
 K_K1, K_LOGK1 = 0, 1
 P_PERIOD, P_LOGPERIOD = 0, 1
@@ -180,6 +182,12 @@ def load():
             raise RvllLibraryError(f"{path} does not export {name}") from exc
         fn.restype = restype
         fn.argtypes = argtypes
+    major, minor = C.c_int32(-1), C.c_int32(-1)
+    lib.rvll_version(C.byref(major), C.byref(minor))
+    if (major.value, minor.value) != ABI_VERSION:      # signatures change with the minor version while it is 0.x
+        raise RvllLibraryError(
+            f"{path} is librvll {major.value}.{minor.value}, these bindings are for {ABI_VERSION[0]}.{ABI_VERSION[1]}: "
+            f"rebuild it (make -C evidence_amd/csrc)")
     _lib = lib
     return lib
 

@@ -248,12 +248,14 @@ void keprv_kernel(const LoglikeArgs a, const double* times, int Nt, unsigned inc
                 ++steps;
             } while (fabs(dE) > a.tol && steps < a.itmax);
             double so, co;
-            sincos_f64(omega, so, co);
+            sincos_any(omega, so, co);
             double rv;
             if (steps >= a.itmax) {
                 rv = K * (co + ecc * co);     // a single time has no "rest of the array": nu stays 0 for this element
             } else {
-                sincos_f64(E, s, c);
+                // E is wherever M is: an absurd period puts both beyond the short reduction's 2^50 (the tile guards its
+                // solves with the |M| < 2^48 bound of the decode step; a curve at arbitrary times has no such bound)
+                sincos_any(E, s, c);
                 const double q = sqrt((1. - ec) * (1. + ec));
                 const double den = __builtin_fma(-ec, c, 1.0);
                 rv = K * (div_exact((c - ec) * co - q * s * so, den) + ecc * co);

@@ -196,6 +196,7 @@ constexpr double kSincosFastMax = 1125899906842624.0;   // 2^50: below, sincos_f
                                                         // constant good to 2^-60 up to there); from here on, reduce_huge
 constexpr int    kSafeSteps = 8;                        // a Newton iterate cannot pass 2^50 before its 8th step (rvll_tile.h)
 constexpr double kExcursionM = 281474976710656.0;       // 2^48
+constexpr double kLongSolveEcc = 0.9;                   // a planet at or above it may hold a wandering solve: its point goes first
 constexpr int    kF32Steps = 16;                        // reduced-precision modes: a solve not settled by then is done in double
 
 // |x| in [2^50, inf), finite (any |x| >= 2^-10 works): r in [-pi/4, pi/4] and the quadrant q (mod 4) with |x| = q pi/2 + r (mod 2 pi)

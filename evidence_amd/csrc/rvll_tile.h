@@ -82,6 +82,11 @@ __device__ __forceinline__ double wave_sum_lane0(double v)
     return v;
 }
 
+// The CU-wide form's ticket word: [0, 16) the ticket count, [16, 26) the wave round the tickets start from, [26, 31) how
+// eccentric the planet that asked for it is (tile_decode: atomicMax before the first ticket is drawn keeps the most
+// eccentric one's round)
+constexpr int kTicketBits = 16, kTicketRoundBits = 10, kTicketRoundMask = (1 << kTicketRoundBits) - 1;
+static_assert(kCuLdsBudget / 8 / kWave < (size_t)kTicketRoundMask, "every wave round of a CU-wide tile has a number");
 // LDS carve-up, all in units of doubles except the int tail.
 constexpr int kPlanetDoubles = (int)(sizeof(rvll_planet) / sizeof(double));
 constexpr int kInstDoubles   = (int)(sizeof(rvll_inst) / sizeof(double));
@@ -250,7 +255,9 @@ struct ItemCtx {
     int* anyfail;
     int* jfail;
     const int* wide;      // != 0: some planet of the tile has |M| beyond 2^48 (absurd period): no solve takes the shortcut
+    int* pflags;          // per-point flag bits (RVLL_FLAG_WANDERED is set from the solver's second loop)
 };
+
 
 // One (point, epoch) item: returns ln sqrt(var) + res^2 / (2 var).
 // FAILCHECK: honour the itmax marks of earlier solves (nu = 0 from the first failing epoch of that planet on).  The
@@ -317,6 +324,9 @@ __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx&
                     // clamp the reference's iteration is thrown out to |E| ~ 1e9 .. 1e22 and finds its way back in
                     // 30 - 350 steps (rvll_math.h, sincos_any): from here on every sin / cos is reduced the long way
                     // where its argument needs it — the same arithmetic, bit for bit, wherever it does not.
+#ifdef RVLL_AB_PRIO               // measured (round 3): raising the wave's priority in here changes nothing (69.4 vs 69.1 us)
+                    __builtin_amdgcn_s_setprio(2);
+#endif
                     int steps = shortcut ? kSafeSteps : 0;
                     do {
                         sincos_any(E, s, c, kc);
@@ -328,6 +338,11 @@ __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx&
                         ++steps;
                     } while (fabs(dE) > a.tol && steps < a.itmax);
                     hit_itmax = steps >= a.itmax;
+                    // more than kSafeSteps steps: the iteration wandered (include/rvll.h, RVLL_FLAG_WANDERED)
+                    if (steps > kSafeSteps) atomicOr(&cx.pflags[pl], RVLL_FLAG_WANDERED);
+#ifdef RVLL_AB_PRIO
+                    __builtin_amdgcn_s_setprio(0);
+#endif
                 }
                 if (hit_itmax) {
                     atomicMin(&cx.jfail[pl * a.Np + ip], j);
@@ -378,11 +393,13 @@ __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx&
                         Ed = En;
                         ++steps;
                     } while (fabs(dd) > a.tol && steps < a.itmax);
+                    if (steps > kSafeSteps) atomicOr(&cx.pflags[pl], RVLL_FLAG_WANDERED);
                     if (steps < a.itmax) {
                         sincos_any(Ed, sd, cd, kc);
                         rv = div_fast(__builtin_fma(p45.x, cd - ec, -(p45.y * sd)), __builtin_fma(-ec, cd, 1.0)) + C0;
                     }
                 } else if (steps < a.itmax) {
+                    if (steps > kSafeSteps) atomicOr(&cx.pflags[pl], RVLL_FLAG_WANDERED);
                     sincos_f32(E, s, c);
                     const float den = __builtin_fmaf(-ecf, c, 1.0f);
                     const float num = __builtin_fmaf((float)p45.x, c - ecf, -((float)p45.y * s));
@@ -551,8 +568,17 @@ __device__ RVLL_DECODE_INLINE void tile_decode(const LoglikeArgs& __restrict__ a
         const double anom = d.anom.idx >= 0 ? ta : d.anom.val;
         const double ma0 = d.anom_kind == RVLL_ANOM_ML0 ? anom - omega : anom;
         const double ec = ecc > 0.99 ? 0.99 : ecc;                  // trueanomaly.c:11-12
+        // a planet this eccentric may hold a solve that wanders for hundreds of steps: the CU-wide form starts its tickets
+        // at the wave round the tile's most eccentric such point begins in (loglike_tile).  Key: eccentricity above the
+        // threshold (0 .. 30: ec <= 0.99) over that round, in the upper bits of the ticket word — atomicMax keeps the most
+        // eccentric; no ticket has been drawn yet (the barrier after this step comes first)
+#ifndef RVLL_AB_NO_ROT
+        if (ec >= kLongSolveEcc)
+            atomicMax(L.ticket, ((int)((ec - kLongSolveEcc) * 340.) << (kTicketBits + kTicketRoundBits)) |
+                                (min((pl * a.Ne) >> 6, kTicketRoundMask) << kTicketBits));
+#endif
         double so, co;
-        sincos_f64(omega, so, co);
+        sincos_any(omega, so, co);                                  // (omega is a free parameter: any finite value)
         const double q = sqrt((1. - ec) * (1. + ec));
         double* P = L.pp + (pl * a.Np + k) * kPlanetFields;
         P[0] = kTwoPi / Pd;
@@ -625,6 +651,9 @@ __device__ __forceinline__ double tile_point_result(const LoglikeArgs& __restric
 {
     int f = L.pflags[pl];
     if (L.anyfail[pl]) f |= RVLL_FLAG_NONCONVERGED;
+    // an invalid orbit is -1e30 whatever the solves of the point's other planets did (the reference never runs them,
+    // rvmodel:198-203): only that bit is reported
+    if (f & RVLL_FLAG_INVALID_ORBIT) f &= RVLL_FLAG_INVALID_ORBIT | kFlagDeferred;
     flags = f;
     const bool invalid = (f & RVLL_FLAG_INVALID_ORBIT) != 0 && a.Np > 0;
     return invalid ? -1e30 : a.cte - L.acc[pl];                            // rvmodel:203, :78-80
@@ -695,7 +724,16 @@ __device__ __forceinline__ __attribute__((flatten)) void loglike_tile(const Logl
     if constexpr (TRACE) { if (tid == 0) tr[DYN ? 3 : 1] = __builtin_amdgcn_s_memrealtime(); }
 
     // 3. items: flattened (point, epoch) pairs of this block, CH at a time
-    const ItemCtx cx{L.pp, L.ins, L.dr, L.lin, L.nfail, L.anyfail, L.jfail, L.wide};
+    const ItemCtx cx{L.pp, L.ins, L.dr, L.lin, L.nfail, L.anyfail, L.jfail, L.wide, L.pflags};
+    // CU-wide form: the point with the most eccentric planet goes FIRST.  One wandering solve keeps its wave busy for
+    // tens of microseconds; drawn late from the ticket counter it is the launch's tail (profiles/r02_long_solve_tail.txt:
+    // 65 -> 73 .. 88 us on the one prior draw in five to ten that holds such a point).  The decode step leaves the wave
+    // round that point starts in IN THE TICKET WORD ITSELF (its upper bits: tile_decode, before any ticket is drawn), so
+    // every ticket arrives with it and the rounds are walked from there, wrapping — every contribution still lands in
+    // its own slot: same sums, same bits.  Nothing new lives in a scalar register across the item loop and nothing more
+    // is fetched per round: the kernel sits at its 106 scalar registers, and every earlier form of this — a register
+    // held across the loop, a second LDS word read next to the ticket — cost all launches 0.5 - 1 us (round 2's three
+    // variants, round 3's first three; profiles/r03_long_solve_tail.txt).
     double* contrib = L.contrib;
     const int nitems = npts * a.Ne;
     // LDS windows are cut at point-local positions — whole points while a point fits the window, otherwise
@@ -709,7 +747,15 @@ __device__ __forceinline__ __attribute__((flatten)) void loglike_tile(const Logl
                 int r = 0;
                 if (lane == 0) r = atomicAdd(L.ticket, 1);
                 r = __builtin_amdgcn_readfirstlane(r);
+#ifndef RVLL_AB_NO_ROT                      // (measurement builds only: scripts/build_variants.sh)
+                const int r0 = (r >> kTicketBits) & kTicketRoundMask;      // where the decode step said to start
+                r &= (1 << kTicketBits) - 1;
                 if (r * kWave >= cend) break;
+                r += r0;
+                if (r * kWave >= cend) r -= (cend + kWave - 1) >> 6;
+#else
+                if (r * kWave >= cend) break;
+#endif
                 const int i = r * kWave + lane;
                 if (i < cend) {
                     int pl, j;

@@ -51,7 +51,7 @@ extern "C" {
 #endif
 
 #define RVLL_VERSION_MAJOR 0
-#define RVLL_VERSION_MINOR 1
+#define RVLL_VERSION_MINOR 2   /* 0.2: rvll_slice_walk takes walker_base; RVLL_FLAG_WANDERED; resident live set */
 
 /* ---- error codes ------------------------------------------------------ */
 #define RVLL_OK             0
@@ -66,6 +66,16 @@ extern "C" {
 /* ---- per-point flag bits written by the log-L kernels ------------------ */
 #define RVLL_FLAG_INVALID_ORBIT  1  /* ecc>1 in a derived parametrisation -> logL=-1e30 */
 #define RVLL_FLAG_NONCONVERGED   2  /* a Kepler solve hit itmax (trueanomaly.c:32-33 path) */
+#define RVLL_FLAG_WANDERED       4  /* a Kepler solve of this point took more than 8 Newton steps.  The reference's
+                                     * iteration (Newton from E = M, stop at |dE| <= 1e-4, trueanomaly.c:17-33) only does
+                                     * that next to a zero of f' = 1 - e cos E at e >= ~0.97, where it is thrown far out
+                                     * and wanders back: where it then stops depends on the last bit of sin / cos, so the
+                                     * reference's own log-L there is only defined to ~1e-9 relative (measured on the
+                                     * oracle with its libm nudged by one ulp).  The contract: every point
+                                     * WITHOUT this bit agrees with the reference to <= 1e-10; a point with it to what
+                                     * the reference agrees with itself.  SURVEY 0.3 / 5: the per-point flag the
+                                     * reference lacks (it ignores the solver's return code, rvmodel/__init__.py:488-492).
+                                     * With RVLL_FLAG_INVALID_ORBIT set, only that bit is reported. */
 
 /* ---- parameter slot: where a model scalar comes from ------------------- */
 /* idx >= 0 : free parameter, value = theta[idx]   (theta ordered as sorted(parnames),

@@ -171,7 +171,7 @@ typedef struct {
     int Ne;
 } rvo_problem;
 
-/* scratch: 6*Ne doubles */
+/* scratch: 7*Ne doubles (the last Ne hold the solver's int32 step counts) */
 static double rvo_loglike_one(const rvo_problem* pb, const double* theta,
                               double* scratch, int32_t* flag_out)
 {
@@ -183,6 +183,7 @@ static double rvo_loglike_one(const rvo_problem* pb, const double* theta,
     double* nu    = scratch + 3 * (size_t)Ne;
     double* ksum  = scratch + 4 * (size_t)Ne;
     double* term  = scratch + 5 * (size_t)Ne;
+    int32_t* steps = (int32_t*)(scratch + 6 * (size_t)Ne);
     int32_t flag = 0;
 
     /* offsets and noise, evidence/rvmodel/__init__.py:181-192 */
@@ -202,8 +203,8 @@ static double rvo_loglike_one(const rvo_problem* pb, const double* theta,
         for (int j = 0; j < Ne; ++j) ksum[j] = 0.;
         for (int ip = 0; ip < L->nplanets; ++ip) {
             planet_pars q = planet_decode(&L->planets[ip], theta);
-            if (!q.valid) {                       /* None -> -1e30, :198-203 */
-                if (flag_out) *flag_out = flag | RVLL_FLAG_INVALID_ORBIT;
+            if (!q.valid) {                       /* None -> -1e30, :198-203; only this bit is reported (rvll.h) */
+                if (flag_out) *flag_out = RVLL_FLAG_INVALID_ORBIT;
                 return -1e30;
             }
             const double w = 2 * M_PI / q.P;                           /* :459 */
@@ -211,9 +212,13 @@ static double rvo_loglike_one(const rvo_problem* pb, const double* theta,
                 ma[j] = w * (pb->time[j] - q.epoch) + q.ma0;
             /* nu pre-zeroed (:488); return code ignored (:490-492) */
             memset(nu, 0, sizeof(double) * (size_t)Ne);
-            if ((rvo_trig_perturb == 0. ? rvo_trueanomaly(ma, Ne, q.ecc, nu, L->itmax, L->tol, NULL)
+            memset(steps, 0, sizeof(int32_t) * (size_t)Ne);
+            if ((rvo_trig_perturb == 0. ? rvo_trueanomaly(ma, Ne, q.ecc, nu, L->itmax, L->tol, steps)
                                         : trueanomaly_nudged(ma, Ne, q.ecc, nu, L->itmax, L->tol)) != 0)
                 flag |= RVLL_FLAG_NONCONVERGED;
+            /* RVLL_FLAG_WANDERED: some solve of the point took more than 8 Newton steps (rvll.h) */
+            for (int j = 0; j < Ne; ++j)
+                if (steps[j] > 8) { flag |= RVLL_FLAG_WANDERED; break; }
             const double ecw = q.ecc * cos(q.omega);
             for (int j = 0; j < Ne; ++j)                               /* :463 */
                 ksum[j] += q.K * (cos(nu[j] + q.omega) + ecw);
@@ -271,7 +276,7 @@ RVO_EXPORT int rvo_loglike_batch(const rvll_layout* L,
     #pragma omp parallel num_threads(nthreads)
 #endif
     {
-        double* scratch = (double*)malloc(sizeof(double) * 6 * (size_t)(Ne > 0 ? Ne : 1));
+        double* scratch = (double*)malloc(sizeof(double) * 7 * (size_t)(Ne > 0 ? Ne : 1));
         if (!scratch) {
             failed = 1;
         } else {

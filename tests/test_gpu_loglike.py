@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import golden
-from evidence_amd import GpuRVModel, FLAG_INVALID_ORBIT
+from evidence_amd import GpuRVModel, FLAG_INVALID_ORBIT, FLAG_WANDERED
 from evidence_amd.synthetic import make_workload
 
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(240)]
@@ -52,7 +52,7 @@ def test_hip_matches_oracle_on_seeded_batches(gpu_required, cfg, n):
         got, flags = m.log_likelihood_batch(theta, return_flags=True)
         layout = m.layout
     om = OracleModel(layout, w.table)
-    ref = om.loglike(theta, nthreads=8)
+    ref, rflags = om.loglike(theta, nthreads=8, return_flags=True)
     err = golden.rel_err(got, ref)
     bad = np.flatnonzero(err > TOL)
     detail = ""
@@ -61,7 +61,8 @@ def test_hip_matches_oracle_on_seeded_batches(gpu_required, cfg, n):
         detail = f"point {i}: err {err[i]:.3e}, steps max {om.iteration_counts(theta[i]).max()}"
     assert bad.size == 0, (cfg, bad.size, detail)
     assert np.percentile(err, 99.9) <= 1e-12
-    assert not flags.any()
+    # flags: nothing invalid, nothing at itmax; RVLL_FLAG_WANDERED exactly where the oracle counted a solve of > 8 steps
+    assert np.array_equal(flags, rflags) and not (flags & ~FLAG_WANDERED).any()
 
 
 @pytest.mark.parametrize("pb", [1, 2, 3, 5, 8, 16, 20, 32])
@@ -298,10 +299,10 @@ def test_high_eccentricity_parity_is_the_references_own_conditioning(gpu_require
     theta[:, ie] = rng.uniform(0.95, 0.9925, n)
     theta[:, names.index("planet2_ecc")] = rng.beta(0.867, 3.03, n)
     with GpuRVModel(case.fixed, case.table, names) as m:
-        got = m.log_likelihood_batch(theta)
+        got, flags = m.log_likelihood_batch(theta, return_flags=True)
         layout = m.layout
     om = OracleModel(layout, case.table)
-    ref = om.loglike(theta, nthreads=8)
+    ref, rflags = om.loglike(theta, nthreads=8, return_flags=True)
     cond = np.maximum(om.conditioning(theta, nthreads=8, eps=-2.0 ** -53), om.conditioning(theta, nthreads=8, eps=2.0 ** -52))
     err = golden.rel_err(got, ref)
     assert err.max() <= 5e-9, float(err.max())                       # (before the long reduction: up to 0.18)
@@ -313,3 +314,15 @@ def test_high_eccentricity_parity_is_the_references_own_conditioning(gpu_require
             assert om.iteration_counts(theta[i]).max() > 12, (int(i), float(err[i]))
     calm = theta[:, ie] < 0.965
     assert err[calm].max() <= 1e-11
+    # The contract of RVLL_FLAG_WANDERED (include/rvll.h): a caller can tell which values are in that
+    # class.  The bit is set exactly where the oracle's own step counts exceed 8; EVERY point without it meets the plain
+    # bar, and every point beyond the bar carries it.
+    wandered = (flags & FLAG_WANDERED) != 0
+    assert np.array_equal(flags, rflags)
+    assert err[~wandered].max() <= TOL, float(err[~wandered].max())
+    assert wandered[err > TOL].all()
+    assert 0 < wandered.sum() < n                                    # (both classes are present in this sample)
+    for i in np.flatnonzero(wandered)[:40]:
+        assert om.iteration_counts(theta[i]).max() > 8
+    for i in np.flatnonzero(~wandered)[:40]:
+        assert om.iteration_counts(theta[i]).max() <= 8

@@ -83,7 +83,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name)
     major, minor = C.c_int32(), C.c_int32()
-    assert lib.rvll_version(C.byref(major), C.byref(minor)) == 0 and (major.value, minor.value) == (0, 1)
+    assert lib.rvll_version(C.byref(major), C.byref(minor)) == 0 and (major.value, minor.value) == _abi.ABI_VERSION
 
 
 def test_struct_sizes_match_the_header_layout():
