@@ -1483,23 +1483,15 @@ int rvll_prior_loglike_batch(rvll_handle* h, const double* cube, int64_t B,
 }
 
 // ---- device-resident slice-sampling walk ---------------------------------------------------------------
-int rvll_slice_walk(rvll_handle* h, double* cube, double* theta, double* logl, int64_t K, double lstar,
-                    const double* chol, const int32_t* wrapped, int32_t nsteps, int32_t max_rounds,
-                    uint64_t seed, int64_t walker_base, int64_t* ncalls)
+}   // extern "C"
+
+namespace {
+
+// device buffers of the walk for K rows (grown on demand)
+int walk_reserve(rvll_handle* h, int64_t K)
 {
-    int rc = use_device(h);
-    if (rc) return rc;
-    if (!h->have_priors) return fail(RVLL_E_NOPRIORS, "rvll_set_priors has not been called");
-    if (K < 0 || nsteps < 0) return fail(RVLL_E_INVALID, "negative size");
-    if (ncalls) *ncalls = 0;
-    if (K == 0 || nsteps == 0) return RVLL_OK;
-    if (!cube || !theta || !logl || !chol) return fail(RVLL_E_INVALID, "null buffer");
-    if (max_rounds < 1 || max_rounds > 4096 || nsteps >= (1 << 18) || K >= (1LL << 31) || walker_base < 0 ||
-        walker_base + K >= (1LL << 32))
-        return fail(RVLL_E_INVALID, "nsteps / max_rounds / K / walker_base out of range");
     const size_t D = (size_t)h->L.ndim;
-    if (D < 1) return fail(RVLL_E_INVALID, "no free parameter to walk in");
-    rc = rvll_dev_reserve(h, K + rvll::kMaxPointsPerBlock);   // scratch rows (one tile per workgroup): d_theta, log-L / flags of lane 0
+    int rc = rvll_dev_reserve(h, K + rvll::kMaxPointsPerBlock);   // scratch rows (one tile per workgroup): d_theta, log-L / flags of lane 0
     if (rc) return rc;
     rc = sync_other_lanes(h);
     if (rc) return rc;
@@ -1525,17 +1517,19 @@ int rvll_slice_walk(rvll_handle* h, double* cube, double* theta, double* logl, i
         }
         h->walk_cap = (long long)cap;
     }
-    std::vector<int32_t> wr(D, 0);
-    if (wrapped) for (size_t k = 0; k < D; ++k) wr[k] = wrapped[k] != 0;
-    hipStream_t st = h->compute;
-    HIP_TRY(hipMemcpyAsync(h->d_walk_u, cube, sizeof(double) * D * (size_t)K, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(h->d_walk_theta, theta, sizeof(double) * D * (size_t)K, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(h->d_walk_logl, logl, sizeof(double) * (size_t)K, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(h->d_walk_chol, chol, sizeof(double) * D * D, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(h->d_walk_wrapped, wr.data(), sizeof(int32_t) * D, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemsetAsync(h->d_walk_ncalls, 0, kWalkWords * sizeof(unsigned long long), st));
-    HIP_TRY(hipStreamSynchronize(st));                 // wr (and pageable sources) may go out of scope
+    return RVLL_OK;
+}
 
+// The walk of the K rows resident in d_walk_u / d_walk_theta / d_walk_logl (chol and wrapped already uploaded): every
+// launch it takes — the first part, the rest (rows dealt to the workgroups by what they cost so far), the full-solver
+// finish of rows the slim kernel deferred — leaves the end points in those buffers.  Synchronises the compute stream.
+int walk_core(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t max_rounds, uint64_t seed,
+              int64_t walker_base, int64_t* ncalls)
+{
+    const size_t D = (size_t)h->L.ndim;
+    hipStream_t st = h->compute;
+    int rc;
+    HIP_TRY(hipMemsetAsync(h->d_walk_ncalls, 0, kWalkWords * sizeof(unsigned long long), st));
     // the walk keeps per-walker state in LDS next to the tile's carve: shrink the group until both fit
     auto walk_args = [&](long long n, rvll::LoglikeArgs* a) -> int {
         int r = build_args(h, h->d_theta, h->d_logL2[0], h->d_flags2[0], n, a);
@@ -1563,23 +1557,32 @@ int rvll_slice_walk(rvll_handle* h, double* cube, double* theta, double* logl, i
     rvll::WalkArgs w{h->d_walk_u, h->d_walk_theta, h->d_walk_logl, h->d_walk_chol, h->d_walk_wrapped, (long long)K,
                      nsteps, max_rounds, (unsigned long long)seed, lstar, h->d_walk_ncalls,
                      h->d_walk_steps, nullptr, nullptr, (long long)walker_base, spec, h->d_walk_ncalls + 1,
-                     h->d_walk_ncalls + kWalkWords - 1, nullptr, nullptr};
+                     h->d_walk_ncalls + kWalkWords - 1, nullptr, nullptr, 0};
     // no more workgroups than the chip holds at once; freed walker slots draw the remaining rows from a queue
     // (RVLL_WALK_QUEUE, a measurement / test switch: 0 = one workgroup per PB rows, as many residency rounds as that
     // takes; n > 0 = as many workgroups as n compute units hold, so that a small walk goes through the queue too)
     const char* qenv = getenv("RVLL_WALK_QUEUE");
     const int max_cus = qenv ? std::max(0, std::min(atoi(qenv), h->n_cu)) : h->n_cu;
-    // With more rows than walker slots the kernel ends in a drain: the rows handed out last still take a whole walk
-    // (phase clock: mean workgroup life 7.2 ms of a 9.5 ms kernel at 16384 rows).  What a row costs per move is a
-    // property of where it walks, so the walk is launched in two parts: the first quarter of the moves for every row,
-    // counting the candidates each one needs; then the rest, rows handed out most expensive first — the late ones are the
-    // short ones.  Results are those of one launch (the moves of a row do not care which launch makes them).
-    // RVLL_WALK_PARTS=1: one launch (measurement switch).
+    // With more rows than walker slots a row handed out late still takes a whole walk — nsteps sequential moves — and the
+    // kernel ends in a drain (phase clock: mean workgroup life 7.2 ms of a 9.5 ms kernel at 16384 rows).  What a row costs
+    // per move is a property of where it walks, so the walk is launched in two parts: the first moves of every row through
+    // the queue (short rows: a fine grain), counting the candidates each one needs; then the rest in the "rows" form —
+    // every workgroup OWNS an equal share of the rows by that cost and interleaves them over its walker slots, so all rows
+    // of the launch end together (rvll_walk.hip, slice_walk_rows_kernel).  Results are those of one launch (the moves of
+    // a row do not care which launch makes them).  RVLL_WALK_PARTS=1: one launch (measurement / test switch).
+    // RVLL_WALK_ROWS=1 selects the rows form; the DEFAULT is the second part through the queue as well, most expensive
+    // rows first (round 2's form): measured on bench.py's nested run (profiles/r03_walk_forms.txt) the rows form balances
+    // the workgroups as designed — and is 7 % slower (1.38 vs 1.48e8 calls/s inside the walk): with every slot always
+    // holding a walker no tile slot is ever free for candidates ahead, and the kernel is bound by what a workgroup's
+    // iteration costs (2600 vector instructions per candidate against the batch kernel's 1990, VALUs busy 75 %), not by
+    // its tail.  Kept, tested bit-identical, for walks whose rows differ more than cfg3's.
     const long long resident = max_cus > 0 ? rvll::slice_walk_resident_blocks(a, !slim, max_cus) : 0;
     const char* penv = getenv("RVLL_WALK_PARTS");
     const bool two_parts = resident > 0 && K > resident * a.PB && nsteps >= 8 && !(penv && atoi(penv) == 1);
+    const char* renv = getenv("RVLL_WALK_ROWS");
+    const bool rows_form = renv && atoi(renv) == 1;
     if (two_parts) {
-        w.nsteps = std::max(1, nsteps / 4);
+        w.nsteps = std::max(1, rows_form ? nsteps / 8 : nsteps / 4);
         if (const char* e = getenv("RVLL_WALK_FIRST")) w.nsteps = std::max(1, std::min(nsteps - 1, atoi(e)));   // measurement switch
         w.cost = h->d_walk_cost;
     }
@@ -1609,59 +1612,80 @@ int rvll_slice_walk(rvll_handle* h, double* cube, double* theta, double* logl, i
         const int64_t K2 = K - nkey0;
         w.nsteps = nsteps;
         w.cost = nullptr;
-        {
-            // the workgroups' first rows: deal the G * PB most expensive ones round the workgroups like cards, so that
-            // every workgroup starts with one of the G longest, one of the next G, ... — eight long rows in one
-            // workgroup would leave it no free tile slot to evaluate candidates ahead with, and they are the critical path
-            const int64_t G = std::min<int64_t>((K2 + a.PB - 1) / a.PB, resident), first_rows = std::min<int64_t>(G * a.PB, K2);
-            std::vector<int32_t> dealt((size_t)first_rows);
-            int64_t k = 0;
-            for (int64_t pl = 0; pl < a.PB; ++pl)
-                for (int64_t b = 0; b < G; ++b) {
-                    const int64_t slot = b * a.PB + pl;
-                    if (slot < first_rows && k < first_rows) dealt[(size_t)slot] = order[(size_t)k++];
-                }
-            std::copy(dealt.begin(), dealt.end(), order.begin());
-        }
-        if (K2 > 0) {
+        w.step_start = h->d_walk_steps;    // every row resumes where the first part left it (read before it is rewritten)
+        if (K2 > 0 && rows_form) {
+            // as many workgroups as the chip holds, every one an equal share of the rows (snake deal of the sorted order,
+            // in the kernel); a share that does not fit the kernel's LDS goes in several launches, one after the other
+            const int64_t G = std::min<int64_t>((K2 + a.PB - 1) / a.PB, resident);
+            int64_t rmax = 1;
+            while (rmax < 4096 && rvll::walk_rows_lds_bytes(a, (int)rmax + 1) <= 60 * 1024) ++rmax;
+            const int64_t chunk = G * rmax;
+            HIP_TRY(hipMemcpyAsync(h->d_walk_order, order.data(), sizeof(int32_t) * (size_t)K2, hipMemcpyHostToDevice, st));
+            for (int64_t lo = 0; lo < K2; lo += chunk) {
+                const int64_t n = std::min<int64_t>(chunk, K2 - lo);
+                // (a chunk of a multi-launch walk takes every chunk-th row of the order, so each holds all cost tiers)
+                rvll::WalkArgs wr = w;
+                wr.K = n;
+                wr.order = h->d_walk_order + lo;
+                const int64_t g = std::min<int64_t>(G, (n + a.PB - 1) / a.PB);
+                wr.rows_per_wg = (int)((n + g - 1) / g);
+                HIP_TRY(rvll::launch_slice_walk_rows(a, wr, !slim, (int)g, st));
+            }
+            HIP_TRY(hipStreamSynchronize(st)); // `order` goes out of scope
+        } else if (K2 > 0) {
+            {
+                // the workgroups' first rows: deal the G * PB most expensive ones round the workgroups like cards, so that
+                // every workgroup starts with one of the G longest, one of the next G, ... — eight long rows in one
+                // workgroup would leave it no free tile slot to evaluate candidates ahead with, and they are the critical path
+                const int64_t G = std::min<int64_t>((K2 + a.PB - 1) / a.PB, resident), first_rows = std::min<int64_t>(G * a.PB, K2);
+                std::vector<int32_t> dealt((size_t)first_rows);
+                int64_t k = 0;
+                for (int64_t pl = 0; pl < a.PB; ++pl)
+                    for (int64_t b = 0; b < G; ++b) {
+                        const int64_t slot = b * a.PB + pl;
+                        if (slot < first_rows && k < first_rows) dealt[(size_t)slot] = order[(size_t)k++];
+                    }
+                std::copy(dealt.begin(), dealt.end(), order.begin());
+            }
             HIP_TRY(hipMemcpyAsync(h->d_walk_order, order.data(), sizeof(int32_t) * (size_t)K2, hipMemcpyHostToDevice, st));
             HIP_TRY(hipMemsetAsync(h->d_walk_ncalls + kWalkWords - 1, 0, sizeof(unsigned long long), st));   // the queue; the counts go on
             w.K = K2;
             w.order = h->d_walk_order;
-            w.step_start = h->d_walk_steps;    // every row resumes where the first part left it (read before it is rewritten)
             HIP_TRY(rvll::launch_slice_walk(a, w, !slim, max_cus, st));
             HIP_TRY(hipStreamSynchronize(st)); // `order` goes out of scope
-            w.K = K;
-            w.order = nullptr;
-            w.step_start = nullptr;
         }
+        w.K = K;
+        w.order = nullptr;
+        w.step_start = nullptr;
     }
-    unsigned long long n = 0, evaluated[kWalkWords] = {};
+    unsigned long long evaluated[kWalkWords] = {};
     h->walk_evaluated = 0;
     std::vector<int32_t> steps(slim ? (size_t)K : 0);
-    HIP_TRY(hipMemcpyAsync(cube, h->d_walk_u, sizeof(double) * D * (size_t)K, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(theta, h->d_walk_theta, sizeof(double) * D * (size_t)K, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(logl, h->d_walk_logl, sizeof(double) * (size_t)K, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(evaluated, h->d_walk_ncalls, sizeof evaluated, hipMemcpyDeviceToHost, st));
     if (slim) HIP_TRY(hipMemcpyAsync(steps.data(), h->d_walk_steps, sizeof(int32_t) * (size_t)K, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    n = evaluated[0];
+    long long total = (long long)evaluated[0];
     h->walk_evaluated = (long long)evaluated[1];
     for (int k = 0; k < 6; ++k) h->walk_phase[k] = evaluated[2 + k];
-    unsigned long long total = n;
     if (slim) {
         std::vector<int32_t> ids, start;
         for (int64_t i = 0; i < K; ++i)
             if (steps[(size_t)i] < nsteps) { ids.push_back((int32_t)i); start.push_back(steps[(size_t)i]); }
         if (!ids.empty()) {
             // finish the interrupted walkers with the full solvers inline: same seed, same walker index in the
-            // random-number counters, resumed at the start of the move that was interrupted
+            // random-number counters, resumed at the start of the move that was interrupted.  Rare: the rows travel
+            // through the host (the whole buffers down, the interrupted rows compacted to their front, walked, and
+            // everything put back)
             const size_t M = ids.size();
-            std::vector<double> su(M * D), sth(M * D), sl(M);
+            std::vector<double> hu(D * (size_t)K), hth(D * (size_t)K), hl((size_t)K), su(M * D), sth(M * D), sl(M);
+            HIP_TRY(hipMemcpyAsync(hu.data(), h->d_walk_u, sizeof(double) * D * (size_t)K, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(hth.data(), h->d_walk_theta, sizeof(double) * D * (size_t)K, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(hl.data(), h->d_walk_logl, sizeof(double) * (size_t)K, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
             for (size_t j = 0; j < M; ++j) {
-                memcpy(&su[j * D], cube + (size_t)ids[j] * D, sizeof(double) * D);
-                memcpy(&sth[j * D], theta + (size_t)ids[j] * D, sizeof(double) * D);
-                sl[j] = logl[ids[j]];
+                memcpy(&su[j * D], &hu[(size_t)ids[j] * D], sizeof(double) * D);
+                memcpy(&sth[j * D], &hth[(size_t)ids[j] * D], sizeof(double) * D);
+                sl[j] = hl[(size_t)ids[j]];
             }
             HIP_TRY(hipMemcpyAsync(h->d_walk_u, su.data(), sizeof(double) * D * M, hipMemcpyHostToDevice, st));
             HIP_TRY(hipMemcpyAsync(h->d_walk_theta, sth.data(), sizeof(double) * D * M, hipMemcpyHostToDevice, st));
@@ -1682,18 +1706,77 @@ int rvll_slice_walk(rvll_handle* h, double* cube, double* theta, double* logl, i
             HIP_TRY(hipMemcpyAsync(sl.data(), h->d_walk_logl, sizeof(double) * M, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipMemcpyAsync(evaluated, h->d_walk_ncalls, sizeof evaluated, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
-            total += evaluated[0];
+            total += (long long)evaluated[0];
             h->walk_evaluated += (long long)evaluated[1];
             for (int k = 0; k < 6; ++k) h->walk_phase[k] += evaluated[2 + k];
             for (size_t j = 0; j < M; ++j) {
-                memcpy(cube + (size_t)ids[j] * D, &su[j * D], sizeof(double) * D);
-                memcpy(theta + (size_t)ids[j] * D, &sth[j * D], sizeof(double) * D);
-                logl[ids[j]] = sl[j];
+                memcpy(&hu[(size_t)ids[j] * D], &su[j * D], sizeof(double) * D);
+                memcpy(&hth[(size_t)ids[j] * D], &sth[j * D], sizeof(double) * D);
+                hl[(size_t)ids[j]] = sl[j];
             }
+            HIP_TRY(hipMemcpyAsync(h->d_walk_u, hu.data(), sizeof(double) * D * (size_t)K, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(h->d_walk_theta, hth.data(), sizeof(double) * D * (size_t)K, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(h->d_walk_logl, hl.data(), sizeof(double) * (size_t)K, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));
         }
     }
     if (ncalls) *ncalls = (int64_t)total;
     h->theta_async = false;
+    return RVLL_OK;
+}
+
+int walk_check_args(rvll_handle* h, int64_t K, int32_t nsteps, int32_t max_rounds, int64_t walker_base)
+{
+    if (!h->have_priors) return fail(RVLL_E_NOPRIORS, "rvll_set_priors has not been called");
+    if (K < 0 || nsteps < 0) return fail(RVLL_E_INVALID, "negative size");
+    if (max_rounds < 1 || max_rounds > 4096 || nsteps >= (1 << 18) || K >= (1LL << 31) || walker_base < 0 ||
+        walker_base + K >= (1LL << 32))
+        return fail(RVLL_E_INVALID, "nsteps / max_rounds / K / walker_base out of range");
+    if (h->L.ndim < 1) return fail(RVLL_E_INVALID, "no free parameter to walk in");
+    return RVLL_OK;
+}
+
+int walk_upload_frame(rvll_handle* h, const double* chol, const int32_t* wrapped)
+{
+    const size_t D = (size_t)h->L.ndim;
+    std::vector<int32_t> wr(D, 0);
+    if (wrapped) for (size_t k = 0; k < D; ++k) wr[k] = wrapped[k] != 0;
+    HIP_TRY(hipMemcpyAsync(h->d_walk_chol, chol, sizeof(double) * D * D, hipMemcpyHostToDevice, h->compute));
+    HIP_TRY(hipMemcpyAsync(h->d_walk_wrapped, wr.data(), sizeof(int32_t) * D, hipMemcpyHostToDevice, h->compute));
+    HIP_TRY(hipStreamSynchronize(h->compute));         // wr (and pageable sources) may go out of scope
+    return RVLL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rvll_slice_walk(rvll_handle* h, double* cube, double* theta, double* logl, int64_t K, double lstar,
+                    const double* chol, const int32_t* wrapped, int32_t nsteps, int32_t max_rounds,
+                    uint64_t seed, int64_t walker_base, int64_t* ncalls)
+{
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (ncalls) *ncalls = 0;
+    rc = walk_check_args(h, K, nsteps, max_rounds, walker_base);
+    if (rc) return rc;
+    if (K == 0 || nsteps == 0) return RVLL_OK;
+    if (!cube || !theta || !logl || !chol) return fail(RVLL_E_INVALID, "null buffer");
+    const size_t D = (size_t)h->L.ndim;
+    rc = walk_reserve(h, K);
+    if (rc) return rc;
+    hipStream_t st = h->compute;
+    HIP_TRY(hipMemcpyAsync(h->d_walk_u, cube, sizeof(double) * D * (size_t)K, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(h->d_walk_theta, theta, sizeof(double) * D * (size_t)K, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(h->d_walk_logl, logl, sizeof(double) * (size_t)K, hipMemcpyHostToDevice, st));
+    rc = walk_upload_frame(h, chol, wrapped);
+    if (rc) return rc;
+    rc = walk_core(h, K, lstar, nsteps, max_rounds, seed, walker_base, ncalls);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(cube, h->d_walk_u, sizeof(double) * D * (size_t)K, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(theta, h->d_walk_theta, sizeof(double) * D * (size_t)K, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(logl, h->d_walk_logl, sizeof(double) * (size_t)K, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     return RVLL_OK;
 }
 

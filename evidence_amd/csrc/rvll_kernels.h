@@ -104,6 +104,7 @@ struct WalkArgs {
     unsigned long long* queue;    // zeroed before the launch: ticket counter of the rows no workgroup started with
     const int32_t* order;         // [K] or null: the order in which rows are handed to walker slots (default: by index)
     int32_t* cost;                // [K] or null, out: candidates every row used in this launch
+    int rows_per_wg;              // the "rows" form (launch_slice_walk_rows): rows every workgroup owns for the whole launch
 };
 constexpr int kWalkCholLds = 48;   // the walk stages a whitening factor of up to 48 x 48 (18 KB) in LDS
 size_t walk_lds_bytes(const LoglikeArgs& a);
@@ -114,6 +115,12 @@ size_t walk_lds_bytes(const LoglikeArgs& a);
 // from w.queue by slots whose walker has finished); 0: one workgroup per PB rows
 hipError_t launch_slice_walk(const LoglikeArgs& a, const WalkArgs& w, bool fat, int max_cus, hipStream_t stream);
 long long slice_walk_resident_blocks(const LoglikeArgs& a, bool fat, int cus);
+// The same walk with the rows dealt to the workgroups in advance (rvll_walk.hip, slice_walk_rows_kernel): nblocks
+// workgroups own w.rows_per_wg rows each (position k of w.order — the host sorts by expected cost — goes to workgroup
+// k mod nblocks, every other tier reversed), park them in LDS and interleave them over their a.PB walker slots at move
+// boundaries, so that all rows end together.  Same results as launch_slice_walk, bit for bit.  No queue, no w.cost needed.
+size_t walk_rows_lds_bytes(const LoglikeArgs& a, int rows_per_wg);
+hipError_t launch_slice_walk_rows(const LoglikeArgs& a, const WalkArgs& w, bool fat, int nblocks, hipStream_t stream);
 
 // ---- scalar-call server: a one-workgroup persistent kernel that answers single-point log-L requests through a
 // block of host-coherent pinned memory, so a scalar callback costs a PCIe round trip instead of a kernel launch

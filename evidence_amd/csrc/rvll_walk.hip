@@ -7,6 +7,9 @@
 // flag would put ~30 extra scalar moves into every Newton iteration, enough to saturate the CU's one scalar unit;
 // they keep the default.)
 #define RVLL_LOCAL_CONSTS 1      // the Newton loop's constants are loaded in front of it, not inside it (rvll_math.h)
+#ifndef RVLL_WALK_WAVES
+#define RVLL_WALK_WAVES 4        // workgroups (= waves per SIMD) of the slim walk kernels a compute unit is to hold
+#endif
 #include <algorithm>
 #include "rvll_tile.h"
 
@@ -47,7 +50,7 @@ namespace {
 // inline, 2 waves per SIMD), whose counter-based random numbers make it retrace the interrupted move exactly — so
 // the pair returns what a FAT-only walk would.
 template <int PREC, bool FAT>
-__global__ __launch_bounds__(kThreads, FAT ? 2 : 4) __attribute__((flatten))
+__global__ __launch_bounds__(kThreads, FAT ? 2 : RVLL_WALK_WAVES) __attribute__((flatten))
 void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
 {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -143,7 +146,8 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
         return true;
     };
     int* const act0 = act;
-    unsigned long long calls = 0, slots = 0;                // the bookkeeping thread only
+    long long calls = 0;                                    // the bookkeeping thread only
+    unsigned long long slots = 0;
     if (tid == kThreads - 1) {                              // walkers that still have moves to make
         int n = 0, nref = 0;
         for (int i = 0; i < nw; ++i) {
@@ -283,7 +287,14 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
                 int fl;
                 const double cl = tile_point_result(a, L, first + j, fl);
                 used = j + 1;
-                if (!FAT && (fl & kFlagDeferred)) { state[pl] = 3; break; }                        // leave at the start of this move
+                if (!FAT && (fl & kFlagDeferred)) {
+                    // leave at the start of this move; the full-solver pass retraces it from its first candidate, so none
+                    // of this move's candidates count here (round_of: the ones of earlier iterations, counted then) —
+                    // ncalls is what the full-solver walk alone reports
+                    state[pl] = 3;
+                    used = -(round_of[pl] - j);
+                    break;
+                }
                 if (cl > w.lstar) { state[pl] = 2; wl[pl] = cl; acc_slot[pl] = first + j; acc_g[pl] = gid[pl]; break; }
                 const double t = slot_t[first + j];
                 if (t < 0.) tmin[pl] = t; else tmax[pl] = t;
@@ -307,7 +318,7 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
             for (int i = 0; i < nw; ++i) refill[i] = 0;                 // last iteration's marks were served at the top
             for (int ai = 0; ai < nact; ++ai) {
                 const int pl = act[ai];
-                calls += (unsigned long long)used_of[pl];
+                calls += used_of[pl];
                 cost_of[pl] += used_of[pl];
                 if (state[pl] == 2) { state[pl] = 0; step_of[pl] += 1; }
                 if (step_of[pl] < w.nsteps && state[pl] != 3) { act_next[n++] = pl; continue; }
@@ -327,13 +338,347 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
         w.u[g * D + k] = wu[pl * D + k];
         if (k == 0) { w.logl[g] = wl[pl]; if (w.steps_done) w.steps_done[g] = step_of[pl]; if (w.cost) w.cost[g] = cost_of[pl]; }
     }
-    if (tid == kThreads - 1 && calls) atomicAdd(w.ncalls, calls);
+    if (tid == kThreads - 1 && calls) atomicAdd(w.ncalls, (unsigned long long)calls);   // (two's complement: a negative share adds up right)
     if (tid == kThreads - 1 && slots && w.nslots) atomicAdd(w.nslots, slots);
 #ifdef RVLL_WALK_TRACE
     if (tid == 0 && w.nslots) {
         for (int k = 0; k < 4; ++k) atomicAdd(w.nslots + 1 + k, ph[k]);
         atomicAdd(w.nslots + 5, 1ull);
         atomicMax(w.nslots + 6, ph[0] + ph[1] + ph[2] + ph[3]);         // the longest workgroup life of the launch(es)
+    }
+#endif
+#undef WALK_STAMP
+}
+
+
+// ---- the same walk with the rows dealt to the workgroups in advance ("rows" form) -------------------------------
+// The queue of slice_walk_kernel hands whole rows to walker slots, and a row is nsteps SEQUENTIAL moves: with about two
+// rows per slot (16384 rows on the chip's 8192 slots) a slot that takes its last row a little before the others end
+// runs a whole row alone — workgroup life mean 7.3 ms in a 9.4 ms kernel (profiles/r02_walk_phase_probe.txt: a quarter of
+// the kernel is that tail).  Handing rows over between workgroups at a finer grain needs device-scope release / acquire,
+// which on this part is an L2 write-back (round 2: time slices through a global ring ran 9x slower).  Here nothing is
+// handed over: workgroup b OWNS rows_per_wg rows for the whole launch — the host sorts the rows by what they cost in the
+// first part of the walk and the kernel deals them snake-wise (tier r of G rows forwards, tier r + 1 backwards), so every
+// workgroup holds the same share of expensive and cheap rows — parks them in LDS (position, log-L, moves done: 22 doubles
+// a row) and INTERLEAVES them over its PB walker slots at move boundaries: a slot whose walker ends a move parks it and
+// takes the parked row that is furthest behind (kRowSlack moves or more).  All rows of a workgroup therefore advance
+// together and end within kRowSlack moves of each other, all workgroups hold equal work, and the kernel ends when the work
+// does.  The random-number counters name the row, so which slot walks which move of which row changes nothing: end points,
+// log-L, theta and ncalls are those of slice_walk_kernel, bit for bit (tests/test_gpu_walk.py).
+constexpr int kRowSlack = 2;
+template <int PREC, bool FAT>
+__global__ __launch_bounds__(kThreads, FAT ? 2 : RVLL_WALK_WAVES) __attribute__((flatten))
+void slice_walk_rows_kernel(const LoglikeArgs a, const WalkArgs w)
+{
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const Carve cv = carve(a.PB, a.D, a.Np, a.Ni, a.nlin, a.CH);
+    const int D = a.D, PB = a.PB, tid = threadIdx.x, R = w.rows_per_wg, G = gridDim.x;
+    const long long w0 = (long long)blockIdx.x * PB;         // the workgroup's scratch rows of the tile
+    const int nw = PB;                                        // tile slots
+    double* wu   = smem + ((cv.total_doubles + 1) & ~1);   // [PB][D] current positions of the walkers in the slots
+    double* dir  = wu + PB * D;
+    double* lo_s = dir + PB * D;
+    double* hi_s = lo_s + PB * D;
+    double* tmin = hi_s + PB * D;
+    double* tmax = tmin + PB;
+    double* slot_t = tmax + PB;
+    double* wl   = slot_t + PB;
+    double* cand = wl + PB;
+    const bool chol_in_lds = D <= kWalkCholLds;
+    double* chol_s = cand + PB * D;
+    double* ru   = chol_s + (chol_in_lds ? D * D : 0);      // [R][D] parked rows: position ...
+    double* rl   = ru + R * D;                              // [R]    ... log-L ...
+    int* act     = reinterpret_cast<int*>(rl + R);
+    int* state   = act + 2 * PB;
+    int* step_of = state + PB;
+    int* round_of = step_of + PB;
+    int* first_of = round_of + PB;
+    int* nsp_of  = first_of + PB;
+    int* acc_slot = nsp_of + PB;
+    int* used_of = acc_slot + PB;
+    int* slot_pl = used_of + PB;
+    int* srow    = slot_pl + PB;                            // [PB] the parked-row index of the walker in the slot, or -1
+    int* park    = srow + PB;                               // [PB] row to park the slot's walker into at the top of the next iteration, or -1
+    int* fetch   = park + PB;                               // [PB] row to load into the slot there, or -1
+    int* acc_g   = fetch + PB;                              // [PB] global row of the walker whose candidate was accepted
+    int* turn    = acc_g + PB;                              // [PB] moves the slot's walker has made since it took the slot
+    int* ring_s  = turn + PB;                               // [2]  the ring of parked rows that wait: head, count
+    int* nact_s  = ring_s + 2;                              // [3]
+    int* wrapped_s = nact_s + 3;                            // [D]
+    int* rrow    = wrapped_s + D;                           // [R] ... global row (or -1: none) ...
+    int* rstep   = rrow + R;                                // [R] ... moves done ...
+    int* rcost   = rstep + R;                               // [R] ... candidates used in this launch ...
+    int* ring    = rcost + R;                               // [R] parked rows with moves left, first in first out
+    const double* chol = chol_in_lds ? chol_s : w.chol;
+    const TileLds L = tile_views(a, smem);
+    const double one_below = 0.99999999999999988898;
+
+    auto row_at = [&](long long k) -> int { return w.order ? w.order[k] : (int)k; };
+    for (int r = tid; r < R; r += kThreads) {
+        const long long pos = (long long)r * G + ((r & 1) ? G - 1 - (int)blockIdx.x : (int)blockIdx.x);    // snake deal
+        const int g = pos < w.K ? row_at(pos) : -1;
+        rrow[r] = g;
+        rcost[r] = 0;
+        rl[r] = g >= 0 ? w.logl[g] : 0.;
+        const int ss = g >= 0 ? (w.step_start ? w.step_start[g] : 0) : w.nsteps;
+        rstep[r] = ss;
+    }
+    __syncthreads();
+    for (int i = tid; i < R * D; i += kThreads) { const int g = rrow[i / D]; ru[i] = g >= 0 ? w.u[(long long)g * D + i % D] : 0.; }
+    if (chol_in_lds) for (int i = tid; i < D * D; i += kThreads) chol_s[i] = w.chol[i];
+    for (int i = tid; i < D; i += kThreads) wrapped_s[i] = w.wrapped[i];
+    for (int i = tid; i < PB; i += kThreads) { state[i] = 0; round_of[i] = 0; srow[i] = -1; park[i] = -1; fetch[i] = -1; step_of[i] = 0; turn[i] = 0; used_of[i] = 0; }
+    const int lane = tid & (kWave - 1);
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
+    if (tid >= kThreads - kWave) {                          // the ring starts with every row that has moves left, in row order
+        int count = 0;
+        for (int r0 = 0; r0 < R; r0 += kWave) {
+            const int r = r0 + lane;
+            const bool has = r < R && rstep[r] < w.nsteps;
+            const unsigned long long m = __ballot(has);
+            if (has) ring[count + __popcll(m & lanes_below)] = r;
+            count += __popcll(m);
+        }
+        if (lane == 0) { ring_s[0] = 0; ring_s[1] = count; }
+    }
+    __syncthreads();
+
+    // Bookkeeping by the LAST WAVE, one lane per walker slot (as one thread walking the slots it was a chain of dependent LDS
+    // reads: a third of a workgroup's life in this form, where most slots change rows at most move boundaries).  A walker
+    // that has ended a move leaves its slot when it is done (all moves made, or deferred) or has made kRowSlack moves
+    // there and a parked row waits; rows that leave with moves left go to the back of the ring, free slots take from its
+    // front — first in, first out is furthest-behind first, because every turn in a slot is the same number of moves.
+    // Positions in the ring come from ballots, so the lanes never wait for one another; a row pushed in this pass is
+    // taken in a later one (its position is stored at the top of the next iteration, where the fetches happen too).
+    long long calls = 0;                                    // per lane of the bookkeeping wave
+    unsigned long long slots = 0;
+    auto bookkeep = [&](int* act_out) {
+        const int pl = lane;
+        const bool slot = pl < PB;
+        const int r = slot ? srow[pl] : -1;
+        const bool active = r >= 0;
+        int st = active ? state[pl] : 1, stp = active ? step_of[pl] : 0, tn = slot ? turn[pl] : 0;
+        if (active) { const int u = used_of[pl]; calls += u; rcost[r] += u; }
+        if (active && st == 2) { st = 0; stp += 1; }
+        const bool boundary = active && st != 1;
+        const bool done = boundary && (st == 3 || stp >= w.nsteps);
+        if (boundary) { tn += 1; rstep[r] = stp; }
+        const bool want = boundary && (done || tn >= kRowSlack);
+        const int head = ring_s[0], navail = ring_s[1];
+        const unsigned long long m_want = __ballot(want);
+        const int ngets = min(__popcll(m_want), navail);
+        const bool gets = want && __popcll(m_want & lanes_below) < navail;
+        const bool leaves = want && (done || gets);
+        const bool pushes = leaves && !done;
+        const unsigned long long m_push = __ballot(pushes);
+        const bool empty = slot && (!active || (leaves && !gets));
+        const unsigned long long m_empty = __ballot(empty);
+        const bool takes = empty && __popcll(m_empty & lanes_below) < navail - ngets;
+        const int ntakes = min(__popcll(m_empty), navail - ngets);
+        int q = -1;
+        if (gets)  q = ring[(head + __popcll(m_want & lanes_below)) % R];
+        if (takes) q = ring[(head + ngets + __popcll(m_empty & lanes_below)) % R];
+        if (pushes) ring[(head + navail + __popcll(m_push & lanes_below)) % R] = r;
+        int rnew = r;
+        if (q >= 0) { rnew = q; st = 0; tn = 0; }
+        else if (leaves) rnew = -1;
+        if (slot) {
+            park[pl] = leaves ? r : -1;
+            fetch[pl] = q;
+            srow[pl] = rnew;
+            state[pl] = st == 3 ? 0 : st;
+            step_of[pl] = stp;
+            turn[pl] = tn;
+            if (q >= 0) round_of[pl] = 0;
+        }
+        // the next iteration's list and its tile slots: every listed walker one, the free ones dealt out evenly, at most
+        // spec_max per walker and never past the move's last round
+        const bool listed = slot && rnew >= 0;
+        const unsigned long long m_act = __ballot(listed);
+        const int n = __popcll(m_act), ai = __popcll(m_act & lanes_below);
+        int S = 0;
+        if (listed) {
+            act_out[ai] = pl;
+            S = min(w.spec_max, n ? nw / n + (ai < nw % n ? 1 : 0) : 0);
+            S = max(1, min(S, w.max_rounds - (st == 0 ? 0 : round_of[pl])));
+        }
+        if (slot) nsp_of[pl] = S;
+        int f = 0;
+        for (int k = 0; k < pl && k < PB; ++k) f += nsp_of[k];
+        if (listed) first_of[pl] = f;
+        if (lane == 63 - __builtin_clzll(m_act | 1ull) && listed) nact_s[1] = f + S;        // the last listed slot: the total
+        const unsigned long long m_swap = __ballot(leaves || q >= 0);
+        if (lane == 0) {
+            nact_s[0] = n;
+            if (n == 0) nact_s[1] = 0;
+            nact_s[2] = m_swap != 0ull ? 1 : 0;
+            ring_s[0] = (head + ngets + ntakes) % R;
+            ring_s[1] = navail - ngets - ntakes + __popcll(m_push);
+        }
+    };
+    int* const act0 = act;
+    if (tid >= kThreads - kWave) bookkeep(act);             // every slot is free: they take the first rows of the ring
+#ifdef RVLL_AB_STAGGER
+    // The workgroups of this form all start together and do the same work per iteration: the four that share a compute
+    // unit would reach their tiles together and their serial phases together.  A start offset (0 .. 3 quarters of an
+    // iteration, by a hash of the workgroup index) spreads them.
+    {
+        unsigned hsh = blockIdx.x * 2654435761u;
+        const unsigned long long wait = ((hsh >> 13) & 3u) * (unsigned long long)RVLL_AB_STAGGER;   // ticks of 10 ns
+        const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - t_start < wait) __builtin_amdgcn_s_sleep(32);
+    }
+#endif
+    __syncthreads();
+#ifdef RVLL_WALK_TRACE
+    unsigned long long ph[5] = {0, 0, 0, 0, 0}, last = __builtin_amdgcn_s_memrealtime();
+#define WALK_STAMP(k) do { if (tid == 0) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); ph[k] += now - last; last = now; } } while (0)
+#else
+#define WALK_STAMP(k) do { } while (0)
+#endif
+    // every iteration consumes at least one candidate of every listed walker: at most R * nsteps * max_rounds of them
+    const long long max_iters = ((long long)w.nsteps * w.max_rounds + 1) * ((long long)R + 1);
+    for (long long iter = 0; iter < max_iters; ++iter) {
+        const int nact = nact_s[0], nslots = nact_s[1], nswap = nact_s[2];
+        if (nswap) {                                        // walkers change places with parked rows (LDS to LDS)
+            for (int i = tid; i < PB * D; i += kThreads) {
+                const int pl = i / D, k = i - pl * D, st = park[pl], ld = fetch[pl];
+                if (st >= 0) { ru[st * D + k] = wu[i]; if (k == 0) rl[st] = wl[pl]; }
+                if (ld >= 0) { wu[i] = ru[ld * D + k]; if (k == 0) { wl[pl] = rl[ld]; step_of[pl] = rstep[ld]; } }
+            }
+            __syncthreads();
+        }
+        if (nact == 0) break;
+        act = act0 + (iter & 1) * PB;
+        int* const act_next = act0 + ((iter + 1) & 1) * PB;
+        for (int i = tid; i < nact * D; i += kThreads) {
+            const int pl = act[i / D], k = i % D;
+            if (state[pl] != 0) continue;
+            const int g = rrow[srow[pl]];
+            const unsigned long long wid = (unsigned long long)(w.walker_base + (w.walker_id ? (long long)w.walker_id[g] : (long long)g));
+            const unsigned long long ctr = (wid << 32) | ((unsigned long long)step_of[pl] << 14) | (unsigned)(2 * k);
+            const double u1 = uniform01(w.seed, ctr), u2 = uniform01(w.seed, ctr + 1);
+            double sn, cs;
+            sincos_f64(kTwoPi * u2, sn, cs);
+            lo_s[pl * D + k] = sqrt(-2. * log(1. - u1)) * cs;
+        }
+        __syncthreads();
+        for (int i = tid; i < nact * D; i += kThreads) {
+            const int pl = act[i / D], k = i % D;
+            if (state[pl] != 0) continue;
+            double acc = 0.;
+            for (int j = 0; j <= k; ++j) acc += chol[k * D + j] * lo_s[pl * D + j];
+            cand[pl * D + k] = acc;
+        }
+        __syncthreads();
+        for (int i = tid; i < nact * D; i += kThreads) {
+            const int pl = act[i / D], k = i % D;
+            if (state[pl] != 0) continue;
+            double n2 = 0.;
+            for (int j = 0; j < D; ++j) n2 += cand[pl * D + j] * cand[pl * D + j];
+            const double d = cand[pl * D + k] * (1. / sqrt(n2)), u = wu[pl * D + k];
+            dir[pl * D + k] = d;
+            double lo = -INFINITY, hi = INFINITY;
+            if (d != 0.) {
+                if (wrapped_s[k]) {
+                    const double half = 0.5 / fabs(d);
+                    lo = -half; hi = half;
+                } else {
+                    const double t0 = (0. - u) / d, t1 = (1. - u) / d;
+                    lo = fmin(t0, t1); hi = fmax(t0, t1);
+                }
+            }
+            lo_s[pl * D + k] = lo; hi_s[pl * D + k] = hi;
+        }
+        __syncthreads();
+        WALK_STAMP(0);
+        for (int ai = tid; ai < nact; ai += kThreads) {
+            const int pl = act[ai];
+            if (state[pl] == 0) {
+                double lo = -INFINITY, hi = INFINITY;
+                for (int k = 0; k < D; ++k) { lo = fmax(lo, lo_s[pl * D + k]); hi = fmin(hi, hi_s[pl * D + k]); }
+                tmin[pl] = lo; tmax[pl] = hi;
+                round_of[pl] = 0;
+                state[pl] = 1;
+            }
+            const int g = rrow[srow[pl]];
+            const unsigned long long wid = (unsigned long long)(w.walker_base + (w.walker_id ? (long long)w.walker_id[g] : (long long)g));
+            const unsigned long long ctr = (wid << 32) | ((unsigned long long)step_of[pl] << 14) | (unsigned)(8192 + round_of[pl]);
+            double lo = tmin[pl], hi = tmax[pl];
+            const int first = first_of[pl], S = nsp_of[pl];
+            for (int j = 0; j < S; ++j) {
+                const double t = lo + (hi - lo) * uniform01(w.seed, ctr + (unsigned)j);
+                slot_t[first + j] = t; slot_pl[first + j] = pl;
+                if (t < 0.) lo = t; else hi = t;
+            }
+        }
+        __syncthreads();
+        for (int i = tid; i < nslots * D; i += kThreads) {
+            const int sl = i / D, k = i - sl * D, pl = slot_pl[sl];
+            double c = wu[pl * D + k] + slot_t[sl] * dir[pl * D + k];
+            if (wrapped_s[k]) c -= floor(c);
+            cand[i] = fmin(fmax(c, 0.), one_below);
+        }
+        __syncthreads();
+        WALK_STAMP(1);
+        loglike_tile<PREC, FAT ? kFusedFull : kFusedSlim>(a, smem, w0, nslots, cand);
+        __builtin_amdgcn_s_setprio(3);
+        __syncthreads();
+        WALK_STAMP(2);
+        for (int ai = tid; ai < nact; ai += kThreads) {
+            const int pl = act[ai];
+            const int first = first_of[pl], S = nsp_of[pl];
+            int used = 0;
+            acc_slot[pl] = -1;
+            for (int j = 0; j < S; ++j) {
+                int fl;
+                const double cl = tile_point_result(a, L, first + j, fl);
+                used = j + 1;
+                if (!FAT && (fl & kFlagDeferred)) {
+                    // leave at the start of this move; the full-solver pass retraces it from its first candidate, so none
+                    // of this move's candidates count here (round_of: the ones of earlier iterations, counted then)
+                    state[pl] = 3;
+                    used = -(round_of[pl] - j);
+                    break;
+                }
+                if (cl > w.lstar) { state[pl] = 2; wl[pl] = cl; acc_slot[pl] = first + j; acc_g[pl] = rrow[srow[pl]]; break; }
+                const double t = slot_t[first + j];
+                if (t < 0.) tmin[pl] = t; else tmax[pl] = t;
+                if (++round_of[pl] >= w.max_rounds) { state[pl] = 0; step_of[pl] += 1; break; }
+            }
+            used_of[pl] = used;
+        }
+        __syncthreads();
+        for (int i = tid; i < nact * D; i += kThreads) {
+            const int ai = i / D, k = i - ai * D, pl = act[ai];
+            const int sl = acc_slot[pl];
+            if (sl < 0) continue;
+            wu[pl * D + k] = cand[sl * D + k];
+            w.theta[(long long)acc_g[pl] * D + k] = L.theta_s[sl * D + k];
+        }
+        if (tid >= kThreads - kWave) {
+            if (lane == 0) slots += (unsigned long long)nslots;
+            bookkeep(act_next);
+        }
+        __syncthreads();
+        WALK_STAMP(3);
+    }
+    // rows go home
+    for (int i = tid; i < R * D; i += kThreads) { const int g = rrow[i / D]; if (g >= 0) w.u[(long long)g * D + i % D] = ru[i]; }
+    for (int r = tid; r < R; r += kThreads) {
+        const int g = rrow[r];
+        if (g < 0) continue;
+        w.logl[g] = rl[r];
+        if (w.steps_done) w.steps_done[g] = rstep[r];
+        if (w.cost) w.cost[g] = rcost[r];
+    }
+    if (tid >= kThreads - kWave && calls) atomicAdd(w.ncalls, (unsigned long long)calls);   // (two's complement: a negative share adds up right)
+    if (tid >= kThreads - kWave && slots && w.nslots) atomicAdd(w.nslots, slots);
+#ifdef RVLL_WALK_TRACE
+    if (tid == 0 && w.nslots) {
+        for (int k = 0; k < 4; ++k) atomicAdd(w.nslots + 1 + k, ph[k]);
+        atomicAdd(w.nslots + 5, 1ull);
+        atomicMax(w.nslots + 6, ph[0] + ph[1] + ph[2] + ph[3]);
     }
 #endif
 #undef WALK_STAMP
@@ -346,6 +691,13 @@ size_t walk_lds_bytes(const LoglikeArgs& a)
     const size_t base = (loglike_lds_bytes(a) + 15) & ~(size_t)15;
     return base + sizeof(double) * ((size_t)5 * a.PB * a.D + 4 * a.PB + (a.D <= kWalkCholLds ? a.D * a.D : 0)) +
            sizeof(int) * (15 * a.PB + 3 + a.D) + 16;
+}
+
+size_t walk_rows_lds_bytes(const LoglikeArgs& a, int R)
+{
+    const size_t base = (loglike_lds_bytes(a) + 15) & ~(size_t)15;
+    return base + sizeof(double) * ((size_t)5 * a.PB * a.D + 4 * a.PB + (a.D <= kWalkCholLds ? a.D * a.D : 0) + (size_t)R * a.D + R) +
+           sizeof(int) * (15 * a.PB + 5 + a.D + 4 * (size_t)R) + 16;
 }
 
 // workgroups of the walk kernel the given number of compute units holds at once (0: the query failed)
@@ -397,6 +749,28 @@ hipError_t launch_slice_walk(const LoglikeArgs& a, const WalkArgs& w, bool fat, 
     }
 #undef RVLL_WALK
 #undef RVLL_WALK_ONE
+    return hipGetLastError();
+}
+
+hipError_t launch_slice_walk_rows(const LoglikeArgs& a, const WalkArgs& w, bool fat, int nblocks, hipStream_t stream)
+{
+    if (w.K <= 0 || w.nsteps <= 0) return hipSuccess;
+    if (!a.cube || !a.theta_out || !a.priors || !a.flags || a.PB * a.D > 4 * kThreads || w.nsteps >= (1 << 18) ||
+        w.max_rounds < 1 || w.max_rounds > 4096 || a.D > 4096 || (!fat && !w.steps_done) || w.spec_max < 1 ||
+        nblocks < 1 || w.rows_per_wg < 1 || (long long)nblocks * w.rows_per_wg < w.K)
+        return hipErrorInvalidValue;
+    const size_t lds = walk_rows_lds_bytes(a, w.rows_per_wg);
+    if (lds > 64 * 1024) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)nblocks), block(kThreads);
+#define RVLL_WALK(PREC)                                                                                              \
+    if (fat) hipLaunchKernelGGL((slice_walk_rows_kernel<PREC, true>), grid, block, lds, stream, a, w);              \
+    else     hipLaunchKernelGGL((slice_walk_rows_kernel<PREC, false>), grid, block, lds, stream, a, w)
+    switch (a.precision) {
+    case RVLL_PREC_MIXED: RVLL_WALK(RVLL_PREC_MIXED); break;
+    case RVLL_PREC_FP32:  RVLL_WALK(RVLL_PREC_FP32); break;
+    default:              RVLL_WALK(RVLL_PREC_FP64); break;
+    }
+#undef RVLL_WALK
     return hipGetLastError();
 }
 
