@@ -378,25 +378,46 @@ def run_extras(out, model, w, theta, B, with_cpu):
         from evidence_amd.nested import run_nested_slice
         model.set_priors(w.priordict())
         vprior, vloglike = make_ultranest_callbacks(model, vectorized=True)
-        inside = {"s": 0.0, "calls": 0, "slots": 0}
+        kw = dict(nlive=32768, kbatch=16384, dlogz=1e-9, max_calls=60_000_000, wrapped=wrapped_params(model.parnames), seed=1)
 
-        def walker(*a):                   # the walk call by itself, and what it evaluated beyond the calls it reports
-            t2 = time.perf_counter()
-            res = model.slice_walk(*a)
-            inside["s"] += time.perf_counter() - t2
-            inside["calls"] += res[3]
-            inside["slots"] += model.slice_walk_evaluated()
-            return res
+        def timed_run(**how):
+            inside = {"s": 0.0, "calls": 0, "slots": 0}
 
-        t1 = time.perf_counter()
-        ns = run_nested_slice(vprior, vloglike, model.ndim, nlive=32768, kbatch=16384, dlogz=1e-9,
-                              max_calls=60_000_000, wrapped=wrapped_params(model.parnames), seed=1,
-                              prior_loglike=model.prior_loglike_batch, walker=walker)
-        out["nested_sampling_end_to_end"] = {"likelihood_calls_per_s": ns.ncall / (time.perf_counter() - t1),
-                                             "calls": int(ns.ncall), "live_points": 32768, "deaths_per_iteration": 16384,
-                                             "walk": "device (rvll_slice_walk)",
-                                             "inside_walk_calls_per_s": inside["calls"] / inside["s"],
-                                             "tile_slots_evaluated_per_call": inside["slots"] / max(1, inside["calls"])}
+            def walker(*a):               # the walk call by itself, and what it evaluated beyond the calls it reports
+                t2 = time.perf_counter()
+                res = model.slice_walk(*a)
+                inside["s"] += time.perf_counter() - t2
+                inside["calls"] += res[3]
+                inside["slots"] += model.slice_walk_evaluated()
+                return res
+
+            class Live:                   # the same for the resident live set: time inside rvll_live_step
+                live_init, live_get, live_dead = model.live_init, model.live_get, model.live_dead
+
+                @staticmethod
+                def live_step(*a, **k):
+                    t2 = time.perf_counter()
+                    res = model.live_step(*a, **k)
+                    inside["s"] += time.perf_counter() - t2
+                    inside["calls"] += res[1]
+                    inside["slots"] += model.slice_walk_evaluated()
+                    return res
+
+            t1 = time.perf_counter()
+            if how.get("live"):
+                ns = run_nested_slice(None, None, model.ndim, live=Live, **kw)
+            else:
+                ns = run_nested_slice(vprior, vloglike, model.ndim, prior_loglike=model.prior_loglike_batch, walker=walker, **kw)
+            el = time.perf_counter() - t1
+            return {"likelihood_calls_per_s": ns.ncall / el, "calls": int(ns.ncall), "seconds": el,
+                    "inside_walk_calls_per_s": inside["calls"] / inside["s"],
+                    "tile_slots_evaluated_per_call": inside["slots"] / max(1, inside["calls"]), "logz": ns.logz}
+
+        res = timed_run(live=True)        # live set resident on the device: indices up, log-L down (rvll_live_step)
+        res.update(live_points=32768, deaths_per_iteration=16384,
+                   walk="device (rvll_live_step: live set, dead points and the walk resident in HBM)")
+        res["host_managed_live_set"] = timed_run(live=False)      # round 2's form: rows through host buffers every iteration
+        out["nested_sampling_end_to_end"] = res
 
     def fip():
         out["fip_periodogram"] = fip_extra(with_cpu)

@@ -99,6 +99,11 @@ PROTOTYPES = {
     "rvll_prior_table_info": (C.c_int, [Handle, C.c_int32, _dp, _ip]),
     "rvll_slice_walk": (C.c_int, [Handle, _dp, _dp, _dp, C.c_int64, C.c_double, _dp, _ip, C.c_int32, C.c_int32,
                                   C.c_uint64, C.c_int64, C.POINTER(C.c_int64)]),
+    "rvll_live_init": (C.c_int, [Handle, _dp, C.c_int64, _dp]),
+    "rvll_live_step": (C.c_int, [Handle, _ip, C.c_int64, _ip, C.c_double, _dp, _ip, C.c_int32, C.c_int32, C.c_uint64,
+                                 C.c_int64, C.POINTER(C.c_int64), _dp, _dp]),
+    "rvll_live_get": (C.c_int, [Handle, _dp, _dp, _dp]),
+    "rvll_live_dead": (C.c_int, [Handle, C.POINTER(C.c_int64), _dp, _dp]),
     "rvll_scalar_server": (C.c_int, [Handle, C.c_int32]),
     "rvll_loglike_batch": (C.c_int, [Handle, _dp, C.c_int64, _dp, _ip]),
     "rvll_prior_batch": (C.c_int, [Handle, _dp, C.c_int64, _dp]),

@@ -235,6 +235,14 @@ struct rvll_handle {
     long long walk_evaluated = 0;               // tile slots the last rvll_slice_walk evaluated (>= its ncalls)
     unsigned long long walk_phase[6] = {};      // diagnostic build (make walktrace): 100 MHz ticks per phase, summed over workgroups; workgroups
 
+    // device-resident live set (rvll_live_*): nested sampling's live points, and the points that died, stay in HBM
+    long long live_n = 0, live_cap = 0;
+    double *d_live_u = nullptr, *d_live_theta = nullptr, *d_live_logl = nullptr;
+    int32_t* d_live_idx = nullptr;              // [2 * live_cap] order, then start rows, of the current step
+    double *d_live_mom = nullptr;               // scratch, mean, covariance of the whitening
+    long long dead_n = 0, dead_cap = 0;
+    double *d_dead_theta = nullptr, *d_dead_logl = nullptr;
+
     hipEvent_t marks[2] = {nullptr, nullptr};   // rvll_dev_mark: HIP events on lane 0's stream
 
     // geometry
@@ -683,6 +691,8 @@ int rvll_destroy(rvll_handle* h)
     dev_free(h->d_theta); dev_free(h->d_cube);
     for (int l = 0; l < kMaxLanes; ++l) { dev_free(h->d_logL2[l]); dev_free(h->d_flags2[l]); dev_free(h->d_gather2[l]); }
     dev_free(h->d_gather_theta);
+    dev_free(h->d_live_u); dev_free(h->d_live_theta); dev_free(h->d_live_logl); dev_free(h->d_live_idx); dev_free(h->d_live_mom);
+    dev_free(h->d_dead_theta); dev_free(h->d_dead_logl);
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     if (h->pin_defer) (void)hipHostFree(h->pin_defer);
@@ -1776,6 +1786,158 @@ int rvll_slice_walk(rvll_handle* h, double* cube, double* theta, double* logl, i
     HIP_TRY(hipMemcpyAsync(cube, h->d_walk_u, sizeof(double) * D * (size_t)K, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(theta, h->d_walk_theta, sizeof(double) * D * (size_t)K, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(logl, h->d_walk_logl, sizeof(double) * (size_t)K, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return RVLL_OK;
+}
+
+// ---- nested sampling with the live points resident on the device -------------------------------------------
+int rvll_live_init(rvll_handle* h, const double* cube, int64_t N, double* logl_out)
+{
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!h->have_priors) return fail(RVLL_E_NOPRIORS, "rvll_set_priors has not been called");
+    if (N < 1 || N >= (1LL << 31) || !cube) return fail(RVLL_E_INVALID, "rvll_live_init: bad arguments");
+    const size_t D = (size_t)std::max(1, h->L.ndim);
+    rc = rvll_dev_upload_cube(h, cube, N);
+    if (rc) return rc;
+    rc = rvll_dev_prior_loglike(h, N);
+    if (rc) return rc;
+    rc = rvll_dev_sync(h);
+    if (rc) return rc;
+    rc = use_device(h);                                  // (elements the table-only prior stage handed over are redone here)
+    if (rc) return rc;
+    if (N > h->live_cap) {
+        dev_free(h->d_live_u); dev_free(h->d_live_theta); dev_free(h->d_live_logl); dev_free(h->d_live_idx);
+        h->live_cap = 0;
+        HIP_TRY(hipMalloc(&h->d_live_u, sizeof(double) * D * (size_t)N));
+        HIP_TRY(hipMalloc(&h->d_live_theta, sizeof(double) * D * (size_t)N));
+        HIP_TRY(hipMalloc(&h->d_live_logl, sizeof(double) * (size_t)N));
+        HIP_TRY(hipMalloc(&h->d_live_idx, sizeof(int32_t) * 2 * (size_t)N));
+        h->live_cap = N;
+    }
+    if (!h->d_live_mom) HIP_TRY(hipMalloc(&h->d_live_mom, sizeof(double) * (rvll::moments_scratch_doubles((int)D) + D + D * D)));
+    hipStream_t st = h->compute;
+    HIP_TRY(hipMemcpyAsync(h->d_live_u, h->d_cube, sizeof(double) * D * (size_t)N, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(h->d_live_theta, h->d_theta, sizeof(double) * D * (size_t)N, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpyAsync(h->d_live_logl, h->d_logL2[h->logl_last], sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice, st));
+    if (logl_out) HIP_TRY(hipMemcpyAsync(logl_out, h->d_live_logl, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    h->live_n = N;
+    h->dead_n = 0;
+    return RVLL_OK;
+}
+
+int rvll_live_step(rvll_handle* h, const int32_t* order, int64_t kdead, const int32_t* start, double lstar,
+                   const double* chol, const int32_t* wrapped, int32_t nsteps, int32_t max_rounds, uint64_t seed,
+                   int64_t walker_base, int64_t* ncalls, double* logl_new, double* chol_out)
+{
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (ncalls) *ncalls = 0;
+    const int64_t N = h->live_n;
+    if (N < 1) return fail(RVLL_E_INVALID, "rvll_live_init has not been called");
+    if (!order || !start || !logl_new || kdead < 1 || kdead >= N) return fail(RVLL_E_INVALID, "rvll_live_step: bad arguments");
+    rc = walk_check_args(h, kdead, nsteps, max_rounds, walker_base);
+    if (rc) return rc;
+    for (int64_t i = 0; i < N; ++i)
+        if (order[i] < 0 || order[i] >= N) return fail(RVLL_E_INVALID, "rvll_live_step: order[%lld] out of range", (long long)i);
+    for (int64_t i = 0; i < kdead; ++i)
+        if (start[i] < 0 || start[i] >= N) return fail(RVLL_E_INVALID, "rvll_live_step: start[%lld] out of range", (long long)i);
+    const size_t D = (size_t)h->L.ndim;
+    const int Di = h->L.ndim;
+    rc = walk_reserve(h, kdead);
+    if (rc) return rc;
+    hipStream_t st = h->compute;
+    int32_t* d_order = h->d_live_idx;
+    int32_t* d_start = h->d_live_idx + h->live_cap;
+    HIP_TRY(hipMemcpyAsync(d_order, order, sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_start, start, sizeof(int32_t) * (size_t)kdead, hipMemcpyHostToDevice, st));
+    // the points that die (rows order[0 .. kdead)) go to the dead store before their rows are overwritten
+    if (h->dead_n + kdead > h->dead_cap) {
+        const long long cap = std::max<long long>(2 * h->dead_cap, h->dead_n + 4 * kdead);
+        double *nt = nullptr, *nl = nullptr;
+        HIP_TRY(hipMalloc(&nt, sizeof(double) * D * (size_t)cap));
+        HIP_TRY(hipMalloc(&nl, sizeof(double) * (size_t)cap));
+        if (h->dead_n) {
+            HIP_TRY(hipMemcpyAsync(nt, h->d_dead_theta, sizeof(double) * D * (size_t)h->dead_n, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipMemcpyAsync(nl, h->d_dead_logl, sizeof(double) * (size_t)h->dead_n, hipMemcpyDeviceToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
+        dev_free(h->d_dead_theta); dev_free(h->d_dead_logl);
+        h->d_dead_theta = nt; h->d_dead_logl = nl; h->dead_cap = cap;
+    }
+    HIP_TRY(rvll::launch_gather_rows(h->d_live_theta, d_order, kdead, Di, h->d_dead_theta + (size_t)h->dead_n * D, st));
+    HIP_TRY(rvll::launch_gather_rows(h->d_live_logl, d_order, kdead, 1, h->d_dead_logl + h->dead_n, st));
+    h->dead_n += kdead;
+    // whitening: the caller's factor, or the covariance of the surviving rows order[kdead .. N) summed on the device (in a
+    // fixed order) and factored here (19 x 19: host arithmetic; + 1e-14 on the diagonal as evidence_amd/nested.py adds)
+    std::vector<double> factor(D * D, 0.);
+    if (chol) {
+        memcpy(factor.data(), chol, sizeof(double) * D * D);
+    } else {
+        double* scratch = h->d_live_mom;
+        double* d_mean = scratch + rvll::moments_scratch_doubles(Di);
+        double* d_cov = d_mean + D;
+        HIP_TRY(rvll::launch_moments(h->d_live_u, d_order + kdead, N - kdead, Di, scratch, d_mean, d_cov, st));
+        std::vector<double> cov(D * D);
+        HIP_TRY(hipMemcpyAsync(cov.data(), d_cov, sizeof(double) * D * D, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (size_t j = 0; j < D; ++j) {                 // Cholesky - Banachiewicz, lower triangle
+            for (size_t l = 0; l <= j; ++l) {
+                double sum = cov[j * D + l] + (j == l ? 1e-14 : 0.);
+                for (size_t m = 0; m < l; ++m) sum -= factor[j * D + m] * factor[l * D + m];
+                if (j == l) {
+                    if (!(sum > 0.)) return fail(RVLL_E_INVALID, "rvll_live_step: the live points' covariance is not positive definite");
+                    factor[j * D + j] = std::sqrt(sum);
+                } else {
+                    factor[j * D + l] = sum / factor[l * D + l];
+                }
+            }
+        }
+    }
+    if (chol_out) memcpy(chol_out, factor.data(), sizeof(double) * D * D);
+    // the walkers start from rows start[0 .. kdead)
+    HIP_TRY(rvll::launch_gather_rows(h->d_live_u, d_start, kdead, Di, h->d_walk_u, st));
+    HIP_TRY(rvll::launch_gather_rows(h->d_live_theta, d_start, kdead, Di, h->d_walk_theta, st));
+    HIP_TRY(rvll::launch_gather_rows(h->d_live_logl, d_start, kdead, 1, h->d_walk_logl, st));
+    rc = walk_upload_frame(h, factor.data(), wrapped);
+    if (rc) return rc;
+    rc = walk_core(h, kdead, lstar, nsteps, max_rounds, seed, walker_base, ncalls);
+    if (rc) return rc;
+    // ... and their end points replace the dead rows
+    HIP_TRY(rvll::launch_scatter_rows(h->d_walk_u, d_order, kdead, Di, h->d_live_u, st));
+    HIP_TRY(rvll::launch_scatter_rows(h->d_walk_theta, d_order, kdead, Di, h->d_live_theta, st));
+    HIP_TRY(rvll::launch_scatter_rows(h->d_walk_logl, d_order, kdead, 1, h->d_live_logl, st));
+    HIP_TRY(hipMemcpyAsync(logl_new, h->d_walk_logl, sizeof(double) * (size_t)kdead, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return RVLL_OK;
+}
+
+int rvll_live_get(rvll_handle* h, double* cube, double* theta, double* logl)
+{
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (h->live_n < 1) return fail(RVLL_E_INVALID, "rvll_live_init has not been called");
+    const size_t D = (size_t)h->L.ndim, N = (size_t)h->live_n;
+    hipStream_t st = h->compute;
+    if (cube) HIP_TRY(hipMemcpyAsync(cube, h->d_live_u, sizeof(double) * D * N, hipMemcpyDeviceToHost, st));
+    if (theta) HIP_TRY(hipMemcpyAsync(theta, h->d_live_theta, sizeof(double) * D * N, hipMemcpyDeviceToHost, st));
+    if (logl) HIP_TRY(hipMemcpyAsync(logl, h->d_live_logl, sizeof(double) * N, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return RVLL_OK;
+}
+
+int rvll_live_dead(rvll_handle* h, int64_t* n_dead, double* theta, double* logl)
+{
+    int rc = use_device(h);
+    if (rc) return rc;
+    if (!n_dead) return fail(RVLL_E_INVALID, "n_dead is null");
+    const int64_t have = h->dead_n, want = (theta || logl) ? std::min<int64_t>(*n_dead, have) : 0;
+    *n_dead = have;
+    const size_t D = (size_t)h->L.ndim;
+    hipStream_t st = h->compute;
+    if (want > 0 && theta) HIP_TRY(hipMemcpyAsync(theta, h->d_dead_theta, sizeof(double) * D * (size_t)want, hipMemcpyDeviceToHost, st));
+    if (want > 0 && logl) HIP_TRY(hipMemcpyAsync(logl, h->d_dead_logl, sizeof(double) * (size_t)want, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return RVLL_OK;
 }

@@ -122,6 +122,13 @@ long long slice_walk_resident_blocks(const LoglikeArgs& a, bool fat, int cus);
 size_t walk_rows_lds_bytes(const LoglikeArgs& a, int rows_per_wg);
 hipError_t launch_slice_walk_rows(const LoglikeArgs& a, const WalkArgs& w, bool fat, int nblocks, hipStream_t stream);
 
+// ---- device-resident live set (rvll_live.hip): row gather / scatter by index; mean and covariance of a subset of rows
+hipError_t launch_gather_rows(const double* src, const int32_t* idx, long long n, int width, double* dst, hipStream_t st);
+hipError_t launch_scatter_rows(const double* src, const int32_t* idx, long long n, int width, double* dst, hipStream_t st);
+size_t moments_scratch_doubles(int D);
+hipError_t launch_moments(const double* u, const int32_t* idx, long long n, int D, double* scratch, double* mean, double* cov,
+                          hipStream_t st);
+
 // ---- scalar-call server: a one-workgroup persistent kernel that answers single-point log-L requests through a
 // block of host-coherent pinned memory, so a scalar callback costs a PCIe round trip instead of a kernel launch
 // and a stream synchronisation.  Host and device share this layout; every field sits on its own cache line.

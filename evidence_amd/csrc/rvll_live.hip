@@ -1,0 +1,117 @@
+// rvll_live.hip — small data-movement kernels of the device-resident live set (rvll_live_*; include/rvll.h): row gather /
+// scatter by index, and the mean and covariance of a subset of rows in a fixed summation order.
+//
+// The reference leaves nested sampling to UltraNest (evidence/ultranest/__init__.py:159-185), whose region slice sampler
+// whitens its directions with the live points' covariance; evidence_amd/nested.py does the same.  With the walk on the
+// device (rvll_walk.hip) what was left on the host per iteration was index copies of the live points and of the walker rows
+// through PCIe (a fifth of the end-to-end time): these kernels keep all of it in HBM.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "rvll_kernels.h"
+
+namespace rvll {
+
+namespace {
+
+constexpr int kMomBlocks = 128;       // partial sums: a fixed number of blocks, so the summation order is fixed
+
+// dst[i][:] = src[idx[i]][:]   (rows of `width` doubles)
+__global__ __launch_bounds__(kThreads)
+void gather_rows_kernel(const double* src, const int32_t* idx, long long n, int width, double* dst)
+{
+    const long long total = n * width;
+    for (long long e = (long long)blockIdx.x * kThreads + threadIdx.x; e < total; e += (long long)gridDim.x * kThreads) {
+        const long long i = e / width;
+        dst[e] = src[(long long)idx[i] * width + (e - i * width)];
+    }
+}
+
+// dst[idx[i]][:] = src[i][:]   (idx holds distinct rows)
+__global__ __launch_bounds__(kThreads)
+void scatter_rows_kernel(const double* src, const int32_t* idx, long long n, int width, double* dst)
+{
+    const long long total = n * width;
+    for (long long e = (long long)blockIdx.x * kThreads + threadIdx.x; e < total; e += (long long)gridDim.x * kThreads) {
+        const long long i = e / width;
+        dst[(long long)idx[i] * width + (e - i * width)] = src[e];
+    }
+}
+
+// partial column sums of the rows idx[0..n): block b takes rows b, b + kMomBlocks, ...; thread d < D one column
+__global__ __launch_bounds__(kThreads)
+void moments_sum_kernel(const double* u, const int32_t* idx, long long n, int D, double* part /*[kMomBlocks][D]*/)
+{
+    for (int d = threadIdx.x; d < D; d += kThreads) {
+        double s = 0.;
+        for (long long i = blockIdx.x; i < n; i += kMomBlocks) s += u[(long long)idx[i] * D + d];
+        part[(long long)blockIdx.x * D + d] = s;
+    }
+}
+
+// out[d] = (sum over blocks, in block order) * scale
+__global__ __launch_bounds__(kThreads)
+void moments_fold_kernel(const double* part, int width, double scale, double* out)
+{
+    for (int d = threadIdx.x; d < width; d += kThreads) {
+        double s = 0.;
+        for (int b = 0; b < kMomBlocks; ++b) s += part[(long long)b * width + d];
+        out[d] = s * scale;
+    }
+}
+
+// partial sums of the centred products (u_j - m_j)(u_l - m_l): thread p one (j, l) pair, rows as above
+__global__ __launch_bounds__(kThreads)
+void moments_cov_kernel(const double* u, const int32_t* idx, long long n, int D, const double* mean,
+                        double* part /*[kMomBlocks][D*D]*/)
+{
+    for (int p = threadIdx.x; p < D * D; p += kThreads) {
+        const int j = p / D, l = p - j * D;
+        const double mj = mean[j], ml = mean[l];
+        double s = 0.;
+        for (long long i = blockIdx.x; i < n; i += kMomBlocks) {
+            const double* row = u + (long long)idx[i] * D;
+            s += (row[j] - mj) * (row[l] - ml);
+        }
+        part[(long long)blockIdx.x * D * D + p] = s;
+    }
+}
+
+int blocks_for(long long total)
+{
+    long long b = (total + kThreads - 1) / kThreads;
+    return (int)(b < 1 ? 1 : b > 8192 ? 8192 : b);
+}
+
+}  // namespace
+
+hipError_t launch_gather_rows(const double* src, const int32_t* idx, long long n, int width, double* dst, hipStream_t st)
+{
+    if (n <= 0 || width <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks_for(n * width)), dim3(kThreads), 0, st, src, idx, n, width, dst);
+    return hipGetLastError();
+}
+
+hipError_t launch_scatter_rows(const double* src, const int32_t* idx, long long n, int width, double* dst, hipStream_t st)
+{
+    if (n <= 0 || width <= 0) return hipSuccess;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(blocks_for(n * width)), dim3(kThreads), 0, st, src, idx, n, width, dst);
+    return hipGetLastError();
+}
+
+size_t moments_scratch_doubles(int D) { return (size_t)kMomBlocks * D * D + (size_t)D; }
+
+// mean[D] and cov[D*D] (divided by n - 1, as numpy's d.T @ d / (n - 1)) of the rows idx[0..n) of u; scratch:
+// moments_scratch_doubles(D) doubles.  Two passes, every sum in a fixed order: the same bits for the same rows.
+hipError_t launch_moments(const double* u, const int32_t* idx, long long n, int D, double* scratch, double* mean, double* cov,
+                          hipStream_t st)
+{
+    if (n <= 0 || D <= 0) return hipErrorInvalidValue;
+    double* part = scratch;
+    hipLaunchKernelGGL(moments_sum_kernel, dim3(kMomBlocks), dim3(kThreads), 0, st, u, idx, n, D, part);
+    hipLaunchKernelGGL(moments_fold_kernel, dim3(1), dim3(kThreads), 0, st, part, D, 1.0 / (double)n, mean);
+    hipLaunchKernelGGL(moments_cov_kernel, dim3(kMomBlocks), dim3(kThreads), 0, st, u, idx, n, D, mean, part);
+    hipLaunchKernelGGL(moments_fold_kernel, dim3(1), dim3(kThreads), 0, st, part, D * D, 1.0 / (double)(n > 1 ? n - 1 : 1), cov);
+    return hipGetLastError();
+}
+
+}  // namespace rvll

@@ -257,6 +257,55 @@ class GpuRVModel:
             int(walker_base), C.byref(ncalls)))
         return cube, theta, logl, int(ncalls.value)
 
+    # ---- live set resident on the device (nested.run_nested_slice(..., live=model)) -----------------------------
+    def live_init(self, cube):
+        """N unit-cube rows -> prior transform -> log-L; the live set stays on the device.  Returns log-L [N]."""
+        cube = self._theta2d(cube)
+        logl = np.empty(cube.shape[0], dtype=np.float64)
+        _abi.check(self._lib.rvll_live_init(self._h, _abi.as_dp(cube), cube.shape[0], _abi.as_dp(logl)))
+        self._live_n = cube.shape[0]
+        return logl
+
+    def live_step(self, order, kdead, start, lstar, wrapped=None, nsteps=10, max_rounds=200, seed=0, walker_base=0,
+                  chol=None, return_chol=False):
+        """One iteration of nested sampling on the resident live set (include/rvll.h, rvll_live_step): rows order[:kdead]
+        die (kept in the device's dead store), kdead walkers start from rows `start`, walk, and replace them.  chol=None:
+        the whitening comes from the surviving rows' covariance, computed on the device.  Returns (logl_new[kdead], ncalls)
+        (+ the factor used with return_chol)."""
+        order = np.ascontiguousarray(order, dtype=np.int32)
+        start = np.ascontiguousarray(start, dtype=np.int32)
+        kdead = int(kdead)
+        if order.shape != (self._live_n,) or start.shape != (kdead,):
+            raise ValueError("order must list every live row, start one row per dying point")
+        wr = None if wrapped is None else np.ascontiguousarray(np.asarray(wrapped, dtype=bool).astype(np.int32))
+        ch = None if chol is None else np.ascontiguousarray(chol, dtype=np.float64)
+        if ch is not None and ch.shape != (self.ndim, self.ndim):
+            raise ValueError("chol must be [ndim, ndim]")
+        logl_new = np.empty(kdead, dtype=np.float64)
+        used = np.empty((self.ndim, self.ndim)) if return_chol else None
+        ncalls = C.c_int64(0)
+        _abi.check(self._lib.rvll_live_step(
+            self._h, _abi.as_ip(order), kdead, _abi.as_ip(start), float(lstar), _abi.as_dp(ch) if ch is not None else None,
+            _abi.as_ip(wr) if wr is not None else None, int(nsteps), int(max_rounds), int(seed) & (2 ** 64 - 1),
+            int(walker_base), C.byref(ncalls), _abi.as_dp(logl_new), _abi.as_dp(used) if used is not None else None))
+        return (logl_new, int(ncalls.value), used) if return_chol else (logl_new, int(ncalls.value))
+
+    def live_get(self):
+        """(cube, theta, logl) of the resident live set."""
+        n = self._live_n
+        u, th, ll = np.empty((n, self.ndim)), np.empty((n, self.ndim)), np.empty(n)
+        _abi.check(self._lib.rvll_live_get(self._h, _abi.as_dp(u), _abi.as_dp(th), _abi.as_dp(ll)))
+        return u, th, ll
+
+    def live_dead(self):
+        """(theta, logl) of every point that died so far, in the order they died."""
+        n = C.c_int64(0)
+        _abi.check(self._lib.rvll_live_dead(self._h, C.byref(n), None, None))
+        th, ll = np.empty((n.value, self.ndim)), np.empty(n.value)
+        if n.value:
+            _abi.check(self._lib.rvll_live_dead(self._h, C.byref(n), _abi.as_dp(th), _abi.as_dp(ll)))
+        return th, ll
+
     def scalar_server(self, enable=True):
         """Answer scalar log_likelihood(x) calls through a persistent kernel polling pinned host memory (a PCIe
         round trip instead of a launch + synchronisation; same bits).  Any other call on this model stops the

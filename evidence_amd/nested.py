@@ -159,7 +159,8 @@ def _stable_argsort(x):
 def run_nested_slice(prior: Callable, loglike: Callable, ndim: int, nlive: Optional[int] = None, kbatch: Optional[int] = None,
                      nsteps: Optional[int] = None, dlogz: float = 0.5, max_iter: int = 10_000_000,
                      max_calls: int = 50_000_000, wrapped=None, seed: int = 0,
-                     prior_loglike: Optional[Callable] = None, walker: Optional[Callable] = None) -> NestedResult:
+                     prior_loglike: Optional[Callable] = None, walker: Optional[Callable] = None,
+                     live=None, live_chol: str = "device") -> NestedResult:
     """Nested sampling with `kbatch` deaths per iteration and batched hit-and-run slice sampling.
 
     `prior_loglike(cubes) -> (theta, logl)`, if given, replaces the prior + loglike pair inside the loop
@@ -167,6 +168,13 @@ def run_nested_slice(prior: Callable, loglike: Callable, ndim: int, nlive: Optio
     `walker(cube, theta, logl, lstar, chol, wrapped, nsteps, max_rounds, seed) -> (cube, theta, logl, ncalls)`,
     if given, runs all `nsteps` moves of all replacement walkers in ONE call (GpuRVModel.slice_walk: the whole
     walk — directions, chords, candidates, prior transform, log-L, accept / shrink — stays on the GPU).
+    `live`, if given (a GpuRVModel), keeps the LIVE SET ITSELF on the GPU (GpuRVModel.live_init / live_step: rvll_live_*):
+    unit-cube rows, theta and log-L of the live points and of the points that died never leave HBM during the run; per
+    iteration the host sends the sort order and the walkers' start rows and reads back the new log-L — what it needs
+    for the sort and the evidence sum.  `prior` / `loglike` / `walker` are then unused.  live_chol="device" (default) takes
+    the whitening from the surviving rows' covariance summed on the device; "host" mirrors the cube rows on the host
+    and factors them exactly as the other paths do — slower, and bit-identical to `walker=model.slice_walk` for a seed
+    (the equivalence test's mode).
 
     Each iteration removes the `kbatch` lowest live points in order (the live count shrinks nlive,
     nlive-1, ... while they die, as in dynamic nested sampling), then draws `kbatch` replacements above
@@ -186,8 +194,16 @@ def run_nested_slice(prior: Callable, loglike: Callable, ndim: int, nlive: Optio
     nsteps = int(nsteps or defaults["nsteps"])
     wrapped = None if wrapped is None else np.asarray(wrapped, dtype=bool)
     u = rng.random((nlive, ndim))
-    theta = np.asarray(prior(u), dtype=np.float64)
-    logl = np.asarray(loglike(theta), dtype=np.float64)
+    if live is not None:
+        if live_chol not in ("device", "host"):
+            raise ValueError(live_chol)
+        theta = None
+        logl = live.live_init(u)
+        if live_chol == "device":
+            u = None                                   # no host mirror of the rows at all
+    else:
+        theta = np.asarray(prior(u), dtype=np.float64)
+        logl = np.asarray(loglike(theta), dtype=np.float64)
     ncall = nlive
     dead_theta, dead_logl, dead_logw = [], [], []
     logz, h, logx = -np.inf, 0.0, 0.0
@@ -209,15 +225,29 @@ def run_nested_slice(prior: Callable, loglike: Callable, ndim: int, nlive: Optio
         a_last = np.exp(big - logz_seq[-1]) * (a_prev + float(np.sum(np.exp(logw - big) * dl)))
         logz, logx = float(logz_seq[-1]), float(logx_seq[-1])
         h = float(a_last - logz)
-        dead_theta.append(theta[dead]); dead_logl.append(dl); dead_logw.append(logw)      # (index arrays: already copies)
+        if live is None:
+            dead_theta.append(theta[dead])                                                # (index arrays: already copies)
+        dead_logl.append(dl); dead_logw.append(logw)
         it += kbatch
         alive = order[kbatch:]
         # whitening from the surviving live points
-        ua = u[alive]
-        d0 = ua - ua.mean(axis=0)
-        cov = d0.T @ d0 / max(1, len(alive) - 1) + 1e-14 * np.eye(ndim)
-        chol = np.linalg.cholesky(cov)
+        chol = None
+        if u is not None:
+            ua = u[alive]
+            d0 = ua - ua.mean(axis=0)
+            cov = d0.T @ d0 / max(1, len(alive) - 1) + 1e-14 * np.eye(ndim)
+            chol = np.linalg.cholesky(cov)
         start = alive[rng.integers(0, len(alive), kbatch)]
+        if live is not None:
+            # the resident live set: order and start rows up, the new log-L of the replaced rows down
+            wl, used = live.live_step(order, kbatch, start, lstar, wrapped, nsteps, 200, int(rng.integers(0, 2 ** 62)), chol=chol)
+            ncall += int(used)
+            logl[dead] = wl
+            if u is not None:
+                u = live.live_get()[0]                                                    # live_chol="host": the mirror
+            if np.max(logl) + logx < logz + np.log(np.expm1(dlogz)):
+                break
+            continue
         wu, wt, wl = u[start], theta[start], logl[start]
         if walker is not None:
             wu, wt, wl, used = walker(wu, wt, wl, lstar, chol, wrapped, nsteps, 200, int(rng.integers(0, 2 ** 62)))
@@ -253,6 +283,9 @@ def run_nested_slice(prior: Callable, loglike: Callable, ndim: int, nlive: Optio
         u[dead], theta[dead], logl[dead] = wu, wt, wl
         if np.max(logl) + logx < logz + np.log(np.expm1(dlogz)):
             break
+    if live is not None:
+        dead_theta = [live.live_dead()[0]]
+        theta = live.live_get()[1]
     logw_live = logx - np.log(nlive) + logl
     logz_final = np.logaddexp(logz, _logaddexp_many(logw_live))
     all_theta = np.vstack([a.reshape(-1, ndim) for a in dead_theta] + [theta])

@@ -256,6 +256,35 @@ int rvll_slice_walk_evaluated(rvll_handle* h, int64_t* evaluated);
  * [5] = the longest workgroup life, in ticks. */
 int rvll_slice_walk_phases(rvll_handle* h, uint64_t out[6]);
 
+/* ---- nested sampling with the live points resident on the device ----------------------------------------------- */
+/* rvll_slice_walk above takes and returns its walkers through host buffers; a sampler built on it ships three row sets
+ * each way per iteration (start points up, end points down) and gathers / scatters them on the host — a fifth of the
+ * end-to-end time of evidence_amd/nested.py at 32768 live points.  With these entry points the live set (unit-cube rows,
+ * theta, log-L) and the points that died stay in HBM for the whole run; per iteration the host sends indices and reads
+ * back log-L — what it needs for the sort and the evidence sum (the part of evidence/ultranest/__init__.py:165-185 that is
+ * the sampler's bookkeeping, not its likelihood calls).
+ *
+ * rvll_live_init   N unit-cube rows -> prior transform -> log-L (as rvll_prior_loglike_batch); the three arrays stay resident;
+ *                  logl_out [N] (may be NULL).  Starts a new run (the dead store is emptied).
+ * rvll_live_step   one iteration: order [N] = the live rows by ascending log-L.  The rows order[0 .. kdead) die — their
+ *                  theta and log-L are appended to the dead store, in that order; kdead walkers start from rows
+ *                  start[0 .. kdead) (the sampler draws them among the survivors order[kdead .. N)), walk nsteps moves
+ *                  inside logL > lstar exactly as rvll_slice_walk does (same kernels, same counter-based random numbers:
+ *                  walker i is row walker_base + i), and their end points replace the dead rows (walker i -> row
+ *                  order[i]).  chol: the whitening factor [ndim, ndim], or NULL to have the covariance of the surviving
+ *                  rows summed on the device (two passes, fixed order) and factored by the library; chol_out (may be
+ *                  NULL) receives the factor that was used.  logl_new [kdead]: the new log-L of rows order[0 .. kdead).
+ * rvll_live_get    the live set as it stands (any pointer may be NULL).
+ * rvll_live_dead   *n_dead in: capacity of theta [*, ndim] / logl [*] in rows (ignored when both are NULL);
+ *                  out: rows in the dead store.  Rows are in the order they died.                                     */
+int rvll_live_init(rvll_handle* h, const double* cube /*[N, ndim]*/, int64_t N, double* logl_out /*[N] or NULL*/);
+int rvll_live_step(rvll_handle* h, const int32_t* order /*[N]*/, int64_t kdead, const int32_t* start /*[kdead]*/,
+                   double lstar, const double* chol /*[ndim, ndim] or NULL*/, const int32_t* wrapped /*[ndim] or NULL*/,
+                   int32_t nsteps, int32_t max_rounds, uint64_t seed, int64_t walker_base, int64_t* ncalls,
+                   double* logl_new /*[kdead]*/, double* chol_out /*[ndim, ndim] or NULL*/);
+int rvll_live_get(rvll_handle* h, double* cube, double* theta, double* logl);
+int rvll_live_dead(rvll_handle* h, int64_t* n_dead, double* theta, double* logl);
+
 /* ---- scalar-callback latency ------------------------------------------------------------------------- */
 /* PolyChord's loglike(theta) is irreducibly scalar (evidence/polychord/__init__.py:166-171): one theta per call.
  * With the server enabled, rvll_loglike_batch(B = 1) is answered by a persistent one-workgroup kernel that polls

@@ -103,6 +103,9 @@ def test_gaussian_evidence_with_the_walk_on_the_device(gpu_required):
         prior, loglike = make_ultranest_callbacks(m, vectorized=True)
         out = [run_nested_slice(prior, loglike, 2, nlive=1000, dlogz=0.01, seed=s, walker=m.slice_walk,
                                 nsteps=10, max_calls=20_000_000) for s in (1, 2, 3)]
+        # ... and with the live set itself resident on the device (whitening summed there too)
+        out += [run_nested_slice(None, None, 2, nlive=1000, dlogz=0.01, seed=s, live=m, nsteps=10, max_calls=20_000_000)
+                for s in (4, 5, 6)]
     for r in out:
         assert abs(r.logz - (-np.log(400.0))) < 4 * r.logzerr + 0.05, (r.logz, r.logzerr)
     assert abs(np.mean([r.logz for r in out]) + np.log(400.0)) < 0.12
@@ -295,3 +298,65 @@ def test_queue_serves_rows_with_nothing_left_to_do_and_a_ragged_last_workgroup(g
                 assert all(np.array_equal(a, b) for a, b in zip(got[:3], ref[:3])) and got[3] == ref[3], (k, pb)
             th_chk, ll_chk = m.prior_loglike_batch(ref[0])
             assert np.array_equal(th_chk, ref[1]) and np.array_equal(ll_chk, ref[2])
+
+
+def test_resident_live_set_is_the_host_managed_run_bit_for_bit(gpu_required):
+    """The live set kept on the device (rvll_live_*; nested.run_nested_slice(live=model)): with the whitening factor
+    computed on the host from a mirror of the rows (live_chol="host") the run is the host-managed one (walker=
+    model.slice_walk) bit for bit — evidence, call count, every sample, weight and log-L, dead points in the order they
+    died — because the same kernels walk the same rows with the same counter-based random numbers; only where the rows
+    live between iterations differs."""
+    w = make_workload(3)
+    with GpuRVModel(w.fixedpardict, w.table, w.parnames, priordict=w.priordict()) as m:
+        prior, loglike = make_ultranest_callbacks(m, vectorized=True)
+        wr = wrapped_params(m.parnames)
+        kw = dict(nlive=3000, kbatch=1000, nsteps=9, dlogz=1e-9, max_calls=400_000, wrapped=wr, seed=4)
+        ref = run_nested_slice(prior, loglike, m.ndim, walker=m.slice_walk, **kw)
+        got = run_nested_slice(None, None, m.ndim, live=m, live_chol="host", **kw)
+        dev = run_nested_slice(None, None, m.ndim, live=m, **kw)                 # whitening summed on the device
+        # the rows the device holds at the end are the run's live points; the dead store holds the rest
+        u, theta, logl = m.live_get()
+        th2, ll2 = m.prior_loglike_batch(u)
+    assert ref.niter >= 3000 and got.niter == ref.niter and got.ncall == ref.ncall
+    assert got.logz == ref.logz and got.information == ref.information
+    assert np.array_equal(got.samples, ref.samples) and np.array_equal(got.logl, ref.logl) and np.array_equal(got.logwt, ref.logwt)
+    assert np.array_equal(th2, theta) and np.array_equal(ll2, logl)
+    assert np.array_equal(dev.samples[-3000:], theta) and dev.samples.shape == ref.samples.shape
+    # the device's covariance differs from numpy's in the last bits (another summation order), so that run takes another
+    # path through the same posterior: same size, same answer within the sampler's own scatter
+    assert dev.niter == ref.niter and abs(dev.ncall - ref.ncall) < 0.1 * ref.ncall
+    assert abs(dev.logz - ref.logz) < 5 * np.hypot(dev.logzerr, ref.logzerr) + 1.0
+
+
+def test_live_step_api_contract(gpu_required):
+    """rvll_live_step by itself: dying rows go to the dead store in order, walkers start from the given rows, end above
+    lstar, replace the dying rows; the device's whitening factor is the Cholesky factor of the surviving rows' covariance."""
+    w = make_workload(2)
+    with GpuRVModel(w.fixedpardict, w.table, w.parnames, priordict=w.priordict()) as m:
+        rng = np.random.default_rng(3)
+        n, k = 900, 300
+        cube = rng.random((n, m.ndim))
+        logl = m.live_init(cube)
+        theta0, ll0 = m.prior_loglike_batch(cube)
+        assert np.array_equal(logl, ll0)
+        order = np.argsort(logl, kind="stable")
+        lstar = logl[order[k - 1]]
+        start = order[k:][rng.integers(0, n - k, k)]
+        wr = wrapped_params(m.parnames)
+        new, used, chol = m.live_step(order, k, start, lstar, wr, nsteps=6, seed=12, return_chol=True)
+        u, theta, ll = m.live_get()
+        dth, dll = m.live_dead()
+        # the same walk through the host-buffer entry point, from the same start rows with the same factor
+        c2, t2, l2, used2 = m.slice_walk(cube[start], theta0[start], logl[start], lstar, chol, wr, nsteps=6, seed=12)
+    assert used == used2 and np.array_equal(new, l2) and (new > lstar).all()
+    assert np.array_equal(u[order[:k]], c2) and np.array_equal(theta[order[:k]], t2) and np.array_equal(ll[order[:k]], l2)
+    keep = order[k:]
+    assert np.array_equal(u[keep], cube[keep]) and np.array_equal(ll[keep], logl[keep])       # survivors untouched
+    assert np.array_equal(dth, theta0[order[:k]]) and np.array_equal(dll, logl[order[:k]])
+    d0 = cube[keep] - cube[keep].mean(axis=0)
+    want = np.linalg.cholesky(d0.T @ d0 / (len(keep) - 1) + 1e-14 * np.eye(m.ndim))
+    assert np.allclose(chol, want, rtol=1e-10, atol=1e-13) and np.allclose(np.triu(chol, 1), 0.0)
+    with GpuRVModel(w.fixedpardict, w.table, w.parnames, priordict=w.priordict()) as m:
+        with pytest.raises(Exception, match="rvll_live_init"):
+            m._live_n = 5
+            m.live_step(np.arange(5), 2, np.array([3, 4]), 0.0)
