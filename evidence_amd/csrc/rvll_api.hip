@@ -258,6 +258,8 @@ struct rvll_handle {
     int nlanes = 1;
     long long gather_cap = 0;
     double* d_gather2[kMaxLanes] = {};
+    double *d_gather_host_in = nullptr, *d_gather_host_out = nullptr;   // rvll_allgather_host: grow-only staging
+    long long gather_host_cap = 0;              // in doubles
     double* d_gather_theta = nullptr;           // [nranks * B_local, D] (rvll_allgather_theta)
     long long gather_theta_cap = 0;             // in rows
     int gather_last = 0;
@@ -690,7 +692,7 @@ int rvll_destroy(rvll_handle* h)
     free_priors(h);
     dev_free(h->d_theta); dev_free(h->d_cube);
     for (int l = 0; l < kMaxLanes; ++l) { dev_free(h->d_logL2[l]); dev_free(h->d_flags2[l]); dev_free(h->d_gather2[l]); }
-    dev_free(h->d_gather_theta);
+    dev_free(h->d_gather_theta); dev_free(h->d_gather_host_in); dev_free(h->d_gather_host_out);
     dev_free(h->d_live_u); dev_free(h->d_live_theta); dev_free(h->d_live_logl); dev_free(h->d_live_idx); dev_free(h->d_live_mom);
     dev_free(h->d_dead_theta); dev_free(h->d_dead_logl);
     if (h->pin_in) (void)hipHostFree(h->pin_in);
@@ -2180,21 +2182,27 @@ int rvll_allgather_host(rvll_handle* h, const double* mine, int64_t n_local, dou
     if (!h->nccl_comm[0]) return fail(RVLL_E_RCCL, "rvll_comm_init has not been called");
     if (!mine || !all || n_local < 1) return fail(RVLL_E_INVALID, "bad allgather_host arguments");
     const size_t total = (size_t)n_local * (size_t)h->nranks;
-    double *d_in = nullptr, *d_out = nullptr;
-    HIP_TRY(hipMalloc(&d_in, sizeof(double) * (size_t)n_local));
-    hipError_t e = hipMalloc(&d_out, sizeof(double) * total);
-    int status = RVLL_OK;
-    if (e == hipSuccess) e = hipMemcpyAsync(d_in, mine, sizeof(double) * (size_t)n_local, hipMemcpyHostToDevice, h->compute);
-    if (e == hipSuccess) {
-        const int r = g_rccl.AllGather(d_in, d_out, (size_t)n_local, kNcclFloat64, h->nccl_comm[0], h->compute);
-        if (r != 0) status = fail(RVLL_E_RCCL, "ncclAllGather failed: %s", g_rccl.GetErrorString(r));
+    // a grow-only pair of device buffers kept in the handle (freed by rvll_destroy): a sharded sampler calls this once
+    // per iteration, and hipMalloc / hipFree per call synchronise the whole device — every lane of every handle
+    // 
+    if ((long long)total > h->gather_host_cap) {
+        HIP_TRY(hipStreamSynchronize(h->compute));
+        dev_free(h->d_gather_host_in); dev_free(h->d_gather_host_out);
+        h->gather_host_cap = 0;
+        const size_t cap = std::max<size_t>(total, 4096);
+        HIP_TRY(hipMalloc(&h->d_gather_host_in, sizeof(double) * cap));      // (n_local <= total)
+        HIP_TRY(hipMalloc(&h->d_gather_host_out, sizeof(double) * cap));
+        h->gather_host_cap = (long long)cap;
     }
-    if (status == RVLL_OK && e == hipSuccess) e = hipMemcpyAsync(all, d_out, sizeof(double) * total, hipMemcpyDeviceToHost, h->compute);
-    if (status == RVLL_OK && e == hipSuccess) e = hipStreamSynchronize(h->compute);
-    if (status == RVLL_OK && e != hipSuccess) status = fail(RVLL_E_HIP, "allgather_host: %s", hipGetErrorString(e));
-    (void)hipStreamSynchronize(h->compute);
-    dev_free(d_in); dev_free(d_out);
-    return status;
+    HIP_TRY(hipMemcpyAsync(h->d_gather_host_in, mine, sizeof(double) * (size_t)n_local, hipMemcpyHostToDevice, h->compute));
+    const int r = g_rccl.AllGather(h->d_gather_host_in, h->d_gather_host_out, (size_t)n_local, kNcclFloat64, h->nccl_comm[0], h->compute);
+    if (r != 0) {
+        (void)hipStreamSynchronize(h->compute);
+        return fail(RVLL_E_RCCL, "ncclAllGather failed: %s", g_rccl.GetErrorString(r));
+    }
+    HIP_TRY(hipMemcpyAsync(all, h->d_gather_host_out, sizeof(double) * total, hipMemcpyDeviceToHost, h->compute));
+    HIP_TRY(hipStreamSynchronize(h->compute));
+    return RVLL_OK;
 }
 
 int rvll_download_gathered_theta(rvll_handle* h, int64_t B_total, double* theta_all)

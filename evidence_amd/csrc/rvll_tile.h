@@ -259,7 +259,7 @@ struct ItemCtx {
 };
 
 
-// One (point, epoch) item: returns ln sqrt(var) + res^2 / (2 var).
+// One (point, epoch) item: returns res^2 / (2 var) (the ln sqrt(var) of rvmodel:80 is summed per point by tile_logdet).
 // FAILCHECK: honour the itmax marks of earlier solves (nu = 0 from the first failing epoch of that planet on).  The
 // first pass over a tile runs without it: the marks can only come from that very pass, and every point that got one
 // is re-evaluated with FAILCHECK afterwards (3b of loglike_tile) — so the normal path carries no reads of the marks.
@@ -427,12 +427,22 @@ __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx&
         rvm += cx.lin[pl * a.nlin + k] * a.linpar[(size_t)k * a.Ne + j];
 
     const double res = y - rvm;                                             // rvmodel:215
+#ifdef RVLL_AB_NO_LOGDET              // (measurement builds only: the normalisation term per item, as up to round 2)
     if constexpr (PREC == RVLL_PREC_FP32) {
         const float rf = (float)res, vf = (float)var;
         return (double)(0.5f * __logf(vf) + div_f32(rf * rf, 2.0f * vf));
     } else {
         return 0.5 * log_pos(var) + div_fast(res * res, 2 * var);           // rvmodel:80
     }
+#else
+    // res^2 / (2 var): the point's ln sqrt(var) terms are summed by tile_logdet, once per point
+    if constexpr (PREC == RVLL_PREC_FP32) {
+        const float rf = (float)res, vf = (float)var;
+        return (double)div_f32(rf * rf, 2.0f * vf);
+    } else {
+        return div_fast(res * res, 2 * var);                                // rvmodel:80
+    }
+#endif
 }
 
 #ifndef RVLL_DECODE_INLINE
@@ -617,6 +627,50 @@ __device__ RVLL_DECODE_INLINE void tile_decode(const LoglikeArgs& __restrict__ a
     }
 }
 
+// 2b. The Gaussian normalisation of every point of the tile, sum_j ln sqrt(var_j) with var_j = sigma_j^2 + jitter^2 of
+//     epoch j's instrument (rvmodel:76-80, :189-192), into acc[pl] — apart from the items, because a logarithm per item was
+//     26 of an item's ~640 vector instructions and a sum of logarithms is the logarithm of a product: sixteen lanes (a
+//     whole wave from 513 epochs on) share a point, lane s multiplies the variances of epochs s, s + 16, ... as
+//     (mantissa product, exponent sum) — four instructions a factor, no range to worry about — takes ONE logarithm,
+//     and a row (wave) tree adds the lanes' values.
+//     The order is the point's own (which epochs a lane takes, the row tree), so the bits depend on nothing but the point
+//     and the epoch table: the same in every kernel form, tile size and shard.  ~36 wave instructions a point at 200
+//     epochs against 81 for the logarithms inside the items.
+template <int NT>
+__device__ __forceinline__ void tile_logdet(const LoglikeArgs& __restrict__ a, const TileLds& L, int npts)
+{
+    // lanes per point: a 16-lane row up to 512 epochs, a whole wave beyond (a function of the epoch count alone, so
+    // that the order of the sum — and with it the bits — is the same whatever the tile, the kernel form or the shard)
+    const int gs = a.Ne > 512 ? kWave : 16;
+    const int tid = threadIdx.x, sub = tid & (gs - 1);
+    for (int pl = tid / gs; pl < npts; pl += NT / gs) {
+        const double* jit = L.ins + pl * a.Ni * 2 + 1;
+        double m = 1.;
+        int e = 0, since = 0;
+#pragma unroll 4
+        for (int j = sub; j < a.Ne; j += gs) {
+            const double var = a.s2[j] + jit[a.inst[j] * 2];
+            m *= __builtin_amdgcn_frexp_mant(var);                 // [0.5, 1): the product cannot overflow ...
+            e += __builtin_amdgcn_frexp_exp(var);
+            if (++since == 512) {                                  // ... and is renormalised long before it could underflow
+                e += __builtin_amdgcn_frexp_exp(m);
+                m = __builtin_amdgcn_frexp_mant(m);
+                since = 0;
+            }
+        }
+        double v = __builtin_fma((double)e, 6.93147180559945286227e-01, log_pos(m));
+        if (gs == kWave) {
+            v = wave_sum_lane0(v);
+        } else {
+            v += lanes_up_row<8>(v);
+            v += lanes_up_row<4>(v);
+            v += lanes_up_row<2>(v);
+            v += lanes_up_row<1>(v);
+        }
+        if (sub == 0) L.acc[pl] = 0.5 * v;
+    }
+}
+
 // Per-point partial sums of the contributions [lo[k], hi[k]) of up to four points held in contrib[.. - base], each
 // in the fixed order every kernel form uses (lane-strided, then the shuffle tree), so the bits do not depend on the
 // launch geometry.  Four points go through the tree together: one point's six dependent cross-lane steps are
@@ -720,6 +774,9 @@ __device__ __forceinline__ __attribute__((flatten)) void loglike_tile(const Logl
     if constexpr (TRACE && DYN) { if (tid == 0) tr[2] = __builtin_amdgcn_s_memrealtime(); }
     tile_decode<NT>(a, L, npts);
     __syncthreads();
+#ifndef RVLL_AB_NO_LOGDET
+    tile_logdet<NT>(a, L, npts);          // acc[pl] is next touched behind the barrier that ends the items (3c)
+#endif
     if constexpr (!DYN) __builtin_amdgcn_s_setprio(0);
     if constexpr (TRACE) { if (tid == 0) tr[DYN ? 3 : 1] = __builtin_amdgcn_s_memrealtime(); }
 

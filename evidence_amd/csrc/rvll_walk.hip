@@ -17,6 +17,17 @@ namespace rvll {
 
 namespace {
 
+// One standard normal from two counter-based uniforms (Box-Muller, the cosine branch): u1 in [0, 1) so 1 - u1 is in
+// (0, 1] — log_pos (rvll_math.h: a third of the library log's instructions) takes it.  Every walk kernel draws its
+// directions through this one function, so every form of the walk sees the same numbers.
+__device__ __forceinline__ double walk_normal(unsigned long long seed, unsigned long long ctr)
+{
+    const double u1 = uniform01(seed, ctr), u2 = uniform01(seed, ctr + 1);
+    double sn, cs;
+    sincos_f64(kTwoPi * u2, sn, cs);
+    return sqrt(-2. * log_pos(1. - u1)) * cs;
+}
+
 // Device-resident slice-sampling walk (rvll_kernels.h, WalkArgs; the scheme of evidence_amd/nested.py
 // run_nested_slice, which follows the reference's UltraNest wrapper: region slice sampling, nsteps moves per new
 // point, circular omega / ml0 — evidence/ultranest/__init__.py:159-175).  Everything a move needs stays on the
@@ -85,8 +96,9 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
     int* refill  = gold + PB;                               // [PB] 0 / 1: send gold home and load gid / 2: send gold home, slot stays empty
     int* acc_g   = refill + PB;                             // [PB] row of the walker whose candidate was accepted (= gid then)
     int* cost_of = acc_g + PB;                              // [PB] candidates the slot's current row has used in this launch
-    int* nact_s  = cost_of + PB;                            // [3]  active walkers, tile slots, slots to refill of this iteration
-    int* wrapped_s = nact_s + 3;                            // [D]  circular parameters
+    int* starts  = cost_of + PB;                            // [PB] the listed walkers that start a move in this iteration
+    int* nact_s  = starts + PB;                             // [4]  active walkers, tile slots, slots to refill, walkers starting a move
+    int* wrapped_s = nact_s + 4;                            // [D]  circular parameters
     const double* chol = chol_in_lds ? chol_s : w.chol;
     const TileLds L = tile_views(a, smem);                  // the tile's results are read back from LDS (tile_point_result)
     const double one_below = 0.99999999999999988898;        // nextafter(1, 0)
@@ -116,7 +128,9 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
             S = max(1, min(S, w.max_rounds - (state[pl] == 0 ? 0 : round_of[pl])));
             first_of[pl] = f; nsp_of[pl] = S; f += S;
         }
-        nact_s[0] = n; nact_s[1] = f;
+        int ns = 0;
+        for (int ai = 0; ai < n; ++ai) if (state[act[ai]] == 0) starts[ns++] = act[ai];
+        nact_s[0] = n; nact_s[1] = f; nact_s[3] = ns;
     };
     // the next row nobody walks yet (rows with nothing left to do are ticked off on the way), or -1
     const long long qbase = (long long)gridDim.x * PB;
@@ -196,21 +210,20 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
         act = act0 + (iter & 1) * PB;
         int* const act_next = act0 + ((iter + 1) & 1) * PB;
         // walkers starting a move: standard normals (Box-Muller on two counter-based uniforms), parked in lo_s ...
-        for (int i = tid; i < nact * D; i += kThreads) {
-            const int pl = act[i / D], k = i % D;
-            if (state[pl] != 0) continue;
+        // (only the walkers that START a move — a third of them per iteration at cfg3 — and those packed into as few waves
+        // as they need: looping over every listed walker and skipping the others kept three partly filled waves busy with
+        // Box-Muller, a tenth of the walk's vector instructions; profiles/r03_walk_forms.txt)
+        const int nstart = nact_s[3];
+        for (int i = tid; i < nstart * D; i += kThreads) {
+            const int pl = starts[i / D], k = i % D;
             const unsigned long long wid = (unsigned long long)(w.walker_base + (w.walker_id ? (long long)w.walker_id[gid[pl]] : (long long)gid[pl]));
             const unsigned long long ctr = (wid << 32) | ((unsigned long long)step_of[pl] << 14) | (unsigned)(2 * k);
-            const double u1 = uniform01(w.seed, ctr), u2 = uniform01(w.seed, ctr + 1);
-            double sn, cs;
-            sincos_f64(kTwoPi * u2, sn, cs);
-            lo_s[pl * D + k] = sqrt(-2. * log(1. - u1)) * cs;
+            lo_s[pl * D + k] = walk_normal(w.seed, ctr);
         }
         __syncthreads();
         // ... direction = chol * z (lower triangular), parked in the candidate rows, which are free until the tile ...
-        for (int i = tid; i < nact * D; i += kThreads) {
-            const int pl = act[i / D], k = i % D;
-            if (state[pl] != 0) continue;
+        for (int i = tid; i < nstart * D; i += kThreads) {
+            const int pl = starts[i / D], k = i % D;
             double acc = 0.;
             for (int j = 0; j <= k; ++j) acc += chol[k * D + j] * lo_s[pl * D + j];
             cand[pl * D + k] = acc;
@@ -218,9 +231,8 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
         __syncthreads();
         // ... unit direction and the chord limits of every coordinate, one lane per (walker, coordinate); every lane
         // sums the walker's norm itself (same order, same bits) rather than wait a barrier for one lane to do it ...
-        for (int i = tid; i < nact * D; i += kThreads) {
-            const int pl = act[i / D], k = i % D;
-            if (state[pl] != 0) continue;
+        for (int i = tid; i < nstart * D; i += kThreads) {
+            const int pl = starts[i / D], k = i % D;
             double n2 = 0.;
             for (int j = 0; j < D; ++j) n2 += cand[pl * D + j] * cand[pl * D + j];
             const double d = cand[pl * D + k] * (1. / sqrt(n2)), u = wu[pl * D + k];
@@ -402,9 +414,10 @@ void slice_walk_rows_kernel(const LoglikeArgs a, const WalkArgs w)
     int* fetch   = park + PB;                               // [PB] row to load into the slot there, or -1
     int* acc_g   = fetch + PB;                              // [PB] global row of the walker whose candidate was accepted
     int* turn    = acc_g + PB;                              // [PB] moves the slot's walker has made since it took the slot
-    int* ring_s  = turn + PB;                               // [2]  the ring of parked rows that wait: head, count
-    int* nact_s  = ring_s + 2;                              // [3]
-    int* wrapped_s = nact_s + 3;                            // [D]
+    int* starts  = turn + PB;                               // [PB] the listed walkers that start a move in this iteration
+    int* ring_s  = starts + PB;                             // [2]  the ring of parked rows that wait: head, count
+    int* nact_s  = ring_s + 2;                              // [4]  active walkers, tile slots, swaps pending, walkers starting a move
+    int* wrapped_s = nact_s + 4;                            // [D]
     int* rrow    = wrapped_s + D;                           // [R] ... global row (or -1: none) ...
     int* rstep   = rrow + R;                                // [R] ... moves done ...
     int* rcost   = rstep + R;                               // [R] ... candidates used in this launch ...
@@ -508,8 +521,12 @@ void slice_walk_rows_kernel(const LoglikeArgs a, const WalkArgs w)
         if (listed) first_of[pl] = f;
         if (lane == 63 - __builtin_clzll(m_act | 1ull) && listed) nact_s[1] = f + S;        // the last listed slot: the total
         const unsigned long long m_swap = __ballot(leaves || q >= 0);
+        const bool begins = listed && st == 0;
+        const unsigned long long m_begin = __ballot(begins);
+        if (begins) starts[__popcll(m_begin & lanes_below)] = pl;
         if (lane == 0) {
             nact_s[0] = n;
+            nact_s[3] = __popcll(m_begin);
             if (n == 0) nact_s[1] = 0;
             nact_s[2] = m_swap != 0ull ? 1 : 0;
             ring_s[0] = (head + ngets + ntakes) % R;
@@ -551,29 +568,24 @@ void slice_walk_rows_kernel(const LoglikeArgs a, const WalkArgs w)
         if (nact == 0) break;
         act = act0 + (iter & 1) * PB;
         int* const act_next = act0 + ((iter + 1) & 1) * PB;
-        for (int i = tid; i < nact * D; i += kThreads) {
-            const int pl = act[i / D], k = i % D;
-            if (state[pl] != 0) continue;
+        const int nstart = nact_s[3];                       // the walkers that start a move, packed (see slice_walk_kernel)
+        for (int i = tid; i < nstart * D; i += kThreads) {
+            const int pl = starts[i / D], k = i % D;
             const int g = rrow[srow[pl]];
             const unsigned long long wid = (unsigned long long)(w.walker_base + (w.walker_id ? (long long)w.walker_id[g] : (long long)g));
             const unsigned long long ctr = (wid << 32) | ((unsigned long long)step_of[pl] << 14) | (unsigned)(2 * k);
-            const double u1 = uniform01(w.seed, ctr), u2 = uniform01(w.seed, ctr + 1);
-            double sn, cs;
-            sincos_f64(kTwoPi * u2, sn, cs);
-            lo_s[pl * D + k] = sqrt(-2. * log(1. - u1)) * cs;
+            lo_s[pl * D + k] = walk_normal(w.seed, ctr);
         }
         __syncthreads();
-        for (int i = tid; i < nact * D; i += kThreads) {
-            const int pl = act[i / D], k = i % D;
-            if (state[pl] != 0) continue;
+        for (int i = tid; i < nstart * D; i += kThreads) {
+            const int pl = starts[i / D], k = i % D;
             double acc = 0.;
             for (int j = 0; j <= k; ++j) acc += chol[k * D + j] * lo_s[pl * D + j];
             cand[pl * D + k] = acc;
         }
         __syncthreads();
-        for (int i = tid; i < nact * D; i += kThreads) {
-            const int pl = act[i / D], k = i % D;
-            if (state[pl] != 0) continue;
+        for (int i = tid; i < nstart * D; i += kThreads) {
+            const int pl = starts[i / D], k = i % D;
             double n2 = 0.;
             for (int j = 0; j < D; ++j) n2 += cand[pl * D + j] * cand[pl * D + j];
             const double d = cand[pl * D + k] * (1. / sqrt(n2)), u = wu[pl * D + k];
@@ -690,14 +702,14 @@ size_t walk_lds_bytes(const LoglikeArgs& a)
 {
     const size_t base = (loglike_lds_bytes(a) + 15) & ~(size_t)15;
     return base + sizeof(double) * ((size_t)5 * a.PB * a.D + 4 * a.PB + (a.D <= kWalkCholLds ? a.D * a.D : 0)) +
-           sizeof(int) * (15 * a.PB + 3 + a.D) + 16;
+           sizeof(int) * (16 * a.PB + 4 + a.D) + 16;
 }
 
 size_t walk_rows_lds_bytes(const LoglikeArgs& a, int R)
 {
     const size_t base = (loglike_lds_bytes(a) + 15) & ~(size_t)15;
     return base + sizeof(double) * ((size_t)5 * a.PB * a.D + 4 * a.PB + (a.D <= kWalkCholLds ? a.D * a.D : 0) + (size_t)R * a.D + R) +
-           sizeof(int) * (15 * a.PB + 5 + a.D + 4 * (size_t)R) + 16;
+           sizeof(int) * (16 * a.PB + 6 + a.D + 4 * (size_t)R) + 16;
 }
 
 // workgroups of the walk kernel the given number of compute units holds at once (0: the query failed)
