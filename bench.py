@@ -570,10 +570,17 @@ def sharded_config_steps(make, rank, ranks, shards, steps, step_of, kick=None, v
                 theta = w.sample_theta(B, seed=4321 + rank)
                 model.dev_upload_theta(theta)
                 step, finish = step_of(model, B)
-                n = max(5, min(steps, 50 if cfg == 4 else 20))
-                for _ in range(3):
-                    step()
-                model.dev_sync()
+                n = max(20, min(steps, 50 if cfg == 4 else 20))
+                # a fresh handle: the clocks fell while it was being set up.  One rank warms up by time; several must all
+                # make the same number of steps (every step holds a collective)
+                t_warm, warm_steps = time.perf_counter(), 0
+                while (time.perf_counter() - t_warm < 0.1) if ranks == 1 else (warm_steps < 60):
+                    for _ in range(3):
+                        step()
+                    warm_steps += 3
+                    model.dev_sync()
+                    if kick:
+                        kick()
                 if verify and not verify(model, B):
                     raise RuntimeError(f"cfg{cfg} {prec}: the gathered log-L does not match the ranks' own values")
                 if kick:

@@ -488,6 +488,7 @@ void make_fused(const rvll_handle* h, const double* d_cube, double* d_theta_out,
     a->priors = h->d_priors;
     a->heavy_dims = h->d_heavy;
     a->n_heavy = h->n_heavy;
+    a->light_dims = h->d_heavy + h->n_heavy;
     a->defer = h->pin_defer_dev;
     a->slim_umax = h->slim_umax;
 }
@@ -796,12 +797,28 @@ int rvll_set_priors(rvll_handle* h, const rvll_prior* priors, int32_t ndim)
     }
     HIP_TRY(hipMalloc(&h->d_priors, sizeof(rvll_prior) * (size_t)std::max(1, ndim)));
     if (ndim) HIP_TRY(hipMemcpy(h->d_priors, dev.data(), sizeof(rvll_prior) * (size_t)ndim, hipMemcpyHostToDevice));
-    std::vector<int32_t> heavy;
+    std::vector<int32_t> heavy, light;
     for (int d = 0; d < ndim; ++d)
-        if (priors[d].kind == RVLL_PRIOR_BETA || priors[d].kind == RVLL_PRIOR_GAMMA) heavy.push_back(d);
-    if (!heavy.empty()) {
-        HIP_TRY(hipMalloc(&h->d_heavy, sizeof(int32_t) * heavy.size()));
-        HIP_TRY(hipMemcpy(h->d_heavy, heavy.data(), sizeof(int32_t) * heavy.size(), hipMemcpyHostToDevice));
+        (priors[d].kind == RVLL_PRIOR_BETA || priors[d].kind == RVLL_PRIOR_GAMMA ? heavy : light).push_back(d);
+    // the light kinds grouped by what their quantile costs (pow / ndtri / exp + log / table search / a division / nothing),
+    // costliest first: in a tile of a few points every wave of the staging step otherwise runs every kind of the model
+    auto cost_class = [&](int32_t d) {
+        switch (priors[d].kind) {
+        case RVLL_PRIOR_JEFFREYS: case RVLL_PRIOR_MODJEFFREYS: case RVLL_PRIOR_SORTED_UNIFORM: case RVLL_PRIOR_SORTED_LOGUNIFORM: return 0;
+        case RVLL_PRIOR_NORMAL: case RVLL_PRIOR_LOGNORMAL: case RVLL_PRIOR_ALPHA: return 1;
+        case RVLL_PRIOR_TRUNCRAYLEIGH: return 2;
+        case RVLL_PRIOR_TABLE: return 3;
+        case RVLL_PRIOR_UNIFORMFREQUENCY: return 4;
+        default: return 5;
+        }
+    };
+    std::stable_sort(light.begin(), light.end(), [&](int32_t x, int32_t y) {
+        return cost_class(x) != cost_class(y) ? cost_class(x) < cost_class(y) : priors[x].kind < priors[y].kind; });
+    {
+        std::vector<int32_t> both(heavy);
+        both.insert(both.end(), light.begin(), light.end());
+        HIP_TRY(hipMalloc(&h->d_heavy, sizeof(int32_t) * std::max<size_t>(1, both.size())));
+        if (!both.empty()) HIP_TRY(hipMemcpy(h->d_heavy, both.data(), sizeof(int32_t) * both.size(), hipMemcpyHostToDevice));
     }
     h->n_heavy = (int)heavy.size();
     h->all_direct = true;
@@ -1038,6 +1055,17 @@ int rvll_dev_sync(rvll_handle* h)
 {
     int rc = use_device(h);
     if (rc) return rc;
+    // A blocking hipStreamSynchronize wakes the caller some tens of microseconds after the stream has drained; a caller
+    // that is about to read a result (a sampler's proposal round, bench.py's 20-step timed region: 1.3 ms) waits on the
+    // stream's status first — a poll costs well under a microsecond — and only falls back to the blocking call when the
+    // work is long (the poll gives up after ~2 ms).
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipStreamQuery(h->compute);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) HIP_TRY(q);
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+    }
     HIP_TRY(hipStreamSynchronize(h->compute));
     rc = sync_other_lanes(h);
     if (rc) return rc;

@@ -51,6 +51,8 @@ struct LoglikeArgs {
     const rvll_prior*  priors;      // [D]
     const int32_t*     heavy_dims;  // [n_heavy] parameters with an iterative quantile (Beta, Gamma)
     int                n_heavy;
+    const int32_t*     light_dims;  // [D - n_heavy] the other parameters, those of one kind next to each other (costliest
+                                    // kinds first): consecutive lanes of the staging step then run the same quantile code
     // slim form of that stage (kFusedSlim): Beta / Gamma quantiles are evaluated by the verified table alone; an
     // element it cannot take (|logit q| > slim_umax, q on the boundary) marks its point kFlagDeferred, sets *defer
     // (may be null) and yields NaN — the host redoes such points through the kernels that carry the full solvers

@@ -500,9 +500,10 @@ __device__ __forceinline__ void tile_stage(const LoglikeArgs& __restrict__ a, co
         // parameters otherwise; parameter-fastest, every wave ran every kind of the model one after the other.  The
         // iterative kinds are dealt from the BACK of the workgroup, so that they run in other waves than the tail of
         // the light ones instead of behind it.  (Same function per element either way: same bits.)
-        for (int i = tid; i < npts * a.D; i += NT) {
-            const int d = i / npts, pl = i - d * npts;
-            if (prior_is_heavy(a.priors[d].kind)) continue;
+        const int n_light = a.D - a.n_heavy;
+        for (int i = tid; i < npts * n_light; i += NT) {
+            const int k = i / npts, pl = i - k * npts;
+            const int d = a.light_dims[k];              // parameters of one kind are neighbours in this order (rvll_set_priors)
             const double v = prior_light(a.priors, a.D, src + pl * a.D, d);
             L.theta_s[pl * a.D + d] = v;
             if (dst) dst[pl * a.D + d] = v;

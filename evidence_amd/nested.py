@@ -146,6 +146,18 @@ def _chord(u, d, wrapped):
     return lo.max(axis=1), hi.min(axis=1)
 
 
+_POOL = None
+
+
+def _helper():
+    """One helper thread for calls that block on the GPU while the host has arithmetic of its own to do."""
+    global _POOL
+    if _POOL is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL = ThreadPoolExecutor(max_workers=1, thread_name_prefix="rvll-live")
+    return _POOL
+
+
 def _stable_argsort(x):
     """np.argsort(x, kind="stable"), by way of the (vectorised, ~8x faster) unstable sort whenever that is provably
     the same permutation: no two equal neighbours in the sorted order means no ties to break."""
@@ -212,10 +224,20 @@ def run_nested_slice(prior: Callable, loglike: Callable, ndim: int, nlive: Optio
         order = _stable_argsort(logl)
         dead = order[:kbatch]
         lstar = logl[dead[-1]]
+        dl = logl[dead]
+        if live is not None and u is None:
+            # the resident live set, whitening on the device: the walk needs nothing of this iteration's evidence
+            # bookkeeping, so it starts first — on a helper thread (the C call releases the interpreter lock) — and the
+            # vectorised sums below run on the host while the GPU walks
+            alive = order[kbatch:]
+            start = alive[rng.integers(0, len(alive), kbatch)]
+            seed_it = int(rng.integers(0, 2 ** 62))
+            pending = _helper().submit(live.live_step, order, kbatch, start, lstar, wrapped, nsteps, 200, seed_it)
+        else:
+            pending = None
         # the kbatch deaths in order, live count nlive - i while they die — vectorised (this loop used to cost more
         # than the likelihood calls): X shrinks by exp(-1/(nlive - i)), w_i = (X_{i-1} - X_i) L_i, Z accumulates,
         # and the information H follows from A = sum_j w_j ln L_j / Z = H + ln Z
-        dl = logl[dead]
         logx_seq = logx - np.cumsum(1.0 / (nlive - np.arange(kbatch)))
         logx_prev = np.concatenate([[logx], logx_seq[:-1]])
         logw = logx_prev + np.log1p(-np.exp(logx_seq - logx_prev)) + dl
@@ -229,6 +251,13 @@ def run_nested_slice(prior: Callable, loglike: Callable, ndim: int, nlive: Optio
             dead_theta.append(theta[dead])                                                # (index arrays: already copies)
         dead_logl.append(dl); dead_logw.append(logw)
         it += kbatch
+        if pending is not None:
+            wl, used = pending.result()
+            ncall += int(used)
+            logl[dead] = wl
+            if np.max(logl) + logx < logz + np.log(np.expm1(dlogz)):
+                break
+            continue
         alive = order[kbatch:]
         # whitening from the surviving live points
         chol = None
@@ -239,12 +268,11 @@ def run_nested_slice(prior: Callable, loglike: Callable, ndim: int, nlive: Optio
             chol = np.linalg.cholesky(cov)
         start = alive[rng.integers(0, len(alive), kbatch)]
         if live is not None:
-            # the resident live set: order and start rows up, the new log-L of the replaced rows down
+            # live_chol="host": order and start rows up, the new log-L of the replaced rows down, and the mirror of the rows
             wl, used = live.live_step(order, kbatch, start, lstar, wrapped, nsteps, 200, int(rng.integers(0, 2 ** 62)), chol=chol)
             ncall += int(used)
             logl[dead] = wl
-            if u is not None:
-                u = live.live_get()[0]                                                    # live_chol="host": the mirror
+            u = live.live_get()[0]
             if np.max(logl) + logx < logz + np.log(np.expm1(dlogz)):
                 break
             continue

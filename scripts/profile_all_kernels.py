@@ -53,6 +53,29 @@ def main():
                               max_calls=(6_000_000 if light else 30_000_000), wrapped=wrapped_params(m.parnames), seed=1,
                               prior_loglike=m.prior_loglike_batch, walker=m.slice_walk)   # slice_walk_kernel<0, false>
         print(f"nested sampling: {ns.ncall} calls in {time.perf_counter() - t0:.2f} s", file=sys.stderr)
+        # round 3: the same run with the live set resident on the device (rvll_live_step: gather / scatter / moments kernels)
+        t0 = time.perf_counter()
+        ns = run_nested_slice(None, None, m.ndim, nlive=32768, kbatch=16384, dlogz=1e-9,
+                              max_calls=(6_000_000 if light else 30_000_000), wrapped=wrapped_params(m.parnames), seed=1, live=m)
+        print(f"nested sampling, resident live set: {ns.ncall} calls in {time.perf_counter() - t0:.2f} s", file=sys.stderr)
+    # prior_heavy_kernel on a shape whose table fails its check: Beta(0.1, 0.2) -> full solver per element
+    from evidence_amd.priors import PriorSpec, prior_constructor     # noqa: E402
+    wr = make_workload(3)
+    for n in (1, 2, 3):
+        wr.input_dict[f"planet{n}"]["ecc"][2] = ["Beta", 0.1, 0.2]
+    with GpuRVModel(wr.fixedpardict, wr.table, wr.parnames, priordict=wr.priordict()) as m:
+        info = m.prior_table_info()
+        print("Beta(0.1, 0.2) tables (measured error, evaluated by interpolation):", info, file=sys.stderr)
+        m.dev_fill_cube(B, seed=8)
+        for _ in range(20 * rep):
+            m.dev_prior(B)
+        m.dev_sync()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            m.dev_prior(B)
+        m.dev_sync()
+        print(f"prior transform with rejected tables: {(time.perf_counter() - t0) / 20 * 1e6:.1f} us per {B} points "
+              f"({B * 20 / (time.perf_counter() - t0):.3e} points/s)", file=sys.stderr)
     for cfg, b, n in ((4, 8192, 100 * rep), (5, 16384, 25 * rep)):      # the 8-GPU shard sizes of cfg4 / cfg5
         wk = make_workload(cfg)
         with GpuRVModel(wk.fixedpardict, wk.table, wk.parnames) as m:
