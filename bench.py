@@ -617,8 +617,8 @@ def run_single(args, w, model, theta, B):
     for _ in range(args.warmup):
         model.dev_loglike(B)
     model.dev_sync()
+    model.dev_mark(0)                            # HIP event on the stream the kernel is launched on (not one of the K steps)
     t0 = time.perf_counter()
-    model.dev_mark(0)                            # HIP event on the stream the kernel is launched on
     for _ in range(args.steps):
         model.dev_loglike(B)
     model.dev_mark(1)

@@ -23,9 +23,18 @@ namespace rvll {
 
 namespace {
 
+#ifdef RVLL_AB_NO_LEAN                 // (measurement builds only: scripts/build_variants.sh)
+constexpr bool kLeanKernels = false;
+#else
+constexpr bool kLeanKernels = true;
+#endif
+
 // The CU-wide form: one 1024-thread workgroup per tile of a.PB points (loglike_tile, NT = 1024, DYN); FUSED as in
 // loglike_kernel
-template <int PREC, bool TRACE, int FUSED = kFusedNone>
+// EXTRAS = false: the instantiation for models without drift and without linear activity terms — most of them, the
+// headline configuration among them: the item loop then carries neither those branches nor the scalar registers they hold
+// across it (the kernel sits at its 106; profiles/r03_isa_budget_loglike_cu.txt)
+template <int PREC, bool TRACE, int FUSED = kFusedNone, bool EXTRAS = true>
 __global__ __launch_bounds__(kCuThreads) __attribute__((flatten))
 void loglike_cu_kernel(const LoglikeArgs a)
 {
@@ -33,12 +42,12 @@ void loglike_cu_kernel(const LoglikeArgs a)
     const long long p0 = (long long)blockIdx.x * a.PB;
     const int npts = (int)min((long long)a.PB, a.B - p0);
     if (npts <= 0) return;
-    loglike_tile<PREC, FUSED, TRACE, kCuThreads, true>(a, smem, p0, npts);
+    loglike_tile<PREC, FUSED, TRACE, kCuThreads, true, EXTRAS>(a, smem, p0, npts);
 }
 
 // 4 workgroups of 256 per CU (4 waves/SIMD): caps the kernel at 128 VGPRs
 // FUSED: kFusedNone (theta rows in) or kFusedSlim (unit-cube rows in, verified-table quantiles; rvll_tile.h)
-template <int PREC, int FUSED>
+template <int PREC, int FUSED, bool EXTRAS = true>
 __global__ __launch_bounds__(kThreads, 4) __attribute__((flatten))      // flatten: the prior routines of the fused
 void loglike_kernel(const LoglikeArgs a)                                // form must live under the same VGPR cap
 {
@@ -46,7 +55,7 @@ void loglike_kernel(const LoglikeArgs a)                                // form 
     const long long p0 = (long long)blockIdx.x * a.PB;
     const int npts = (int)min((long long)a.PB, a.B - p0);
     if (npts <= 0) return;
-    loglike_tile<PREC, FUSED>(a, smem, p0, npts);
+    loglike_tile<PREC, FUSED, false, kThreads, false, EXTRAS>(a, smem, p0, npts);
 }
 
 // Diagnostic twin of loglike_kernel<RVLL_PREC_FP64, kFusedNone>: same tile, same launch bounds, plus the stamps.
@@ -340,7 +349,10 @@ hipError_t launch_loglike(const LoglikeArgs& a, hipStream_t stream)
     switch (a.precision) {
     case RVLL_PREC_MIXED: hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_MIXED, kFusedNone>), grid, block, lds, stream, a); break;
     case RVLL_PREC_FP32:  hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP32, kFusedNone>), grid, block, lds, stream, a); break;
-    default:              hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP64, kFusedNone>), grid, block, lds, stream, a); break;
+    default:
+        if (kLeanKernels && !a.has_drift && a.nlin == 0) hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP64, kFusedNone, false>), grid, block, lds, stream, a);
+        else                             hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP64, kFusedNone>), grid, block, lds, stream, a);
+        break;
     }
     return hipGetLastError();
 }
@@ -364,6 +376,7 @@ hipError_t launch_loglike_cu(const LoglikeArgs& a, int grid, hipStream_t stream)
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(loglike_cu_kernel<RVLL_PREC_MIXED, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(loglike_cu_kernel<RVLL_PREC_FP32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(loglike_cu_kernel<RVLL_PREC_FP64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(loglike_cu_kernel<RVLL_PREC_FP64, false, kFusedNone, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(loglike_cu_kernel<RVLL_PREC_FP64, false, kFusedSlim>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(loglike_cu_kernel<RVLL_PREC_MIXED, false, kFusedSlim>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(loglike_cu_kernel<RVLL_PREC_FP32, false, kFusedSlim>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
@@ -383,7 +396,10 @@ hipError_t launch_loglike_cu(const LoglikeArgs& a, int grid, hipStream_t stream)
     switch (a.precision) {
     case RVLL_PREC_MIXED: hipLaunchKernelGGL((loglike_cu_kernel<RVLL_PREC_MIXED, false>), g, block, lds, stream, a); break;
     case RVLL_PREC_FP32:  hipLaunchKernelGGL((loglike_cu_kernel<RVLL_PREC_FP32, false>), g, block, lds, stream, a); break;
-    default:              hipLaunchKernelGGL((loglike_cu_kernel<RVLL_PREC_FP64, false>), g, block, lds, stream, a); break;
+    default:
+        if (kLeanKernels && !a.has_drift && a.nlin == 0) hipLaunchKernelGGL((loglike_cu_kernel<RVLL_PREC_FP64, false, kFusedNone, false>), g, block, lds, stream, a);
+        else                             hipLaunchKernelGGL((loglike_cu_kernel<RVLL_PREC_FP64, false>), g, block, lds, stream, a);
+        break;
     }
     return hipGetLastError();
 }

@@ -263,7 +263,8 @@ struct ItemCtx {
 // FAILCHECK: honour the itmax marks of earlier solves (nu = 0 from the first failing epoch of that planet on).  The
 // first pass over a tile runs without it: the marks can only come from that very pass, and every point that got one
 // is re-evaluated with FAILCHECK afterwards (3b of loglike_tile) — so the normal path carries no reads of the marks.
-template <int PREC, bool FAILCHECK>
+// EXTRAS = false: a model without drift and without linear activity terms (the kernel never looks at those switches)
+template <int PREC, bool FAILCHECK, bool EXTRAS = true>
 __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx& cx, int pl, int j)
 {
     const double t  = a.t[j];
@@ -417,14 +418,16 @@ __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx&
         rvm += ksum;                                                        // rvmodel:199
     }
 
-    if (a.has_drift) {                                                      // rvmodel:242-271
-        const double* d = cx.dr + pl * 6;
-        const double tt = (t - d[4]) * (1.0 / 365.25);
-        const double t2 = tt * tt;
-        rvm += d[0] * tt + d[1] * t2 + d[2] * (t2 * tt) + d[3] * (t2 * t2);
+    if constexpr (EXTRAS) {
+        if (a.has_drift) {                                                  // rvmodel:242-271
+            const double* d = cx.dr + pl * 6;
+            const double tt = (t - d[4]) * (1.0 / 365.25);
+            const double t2 = tt * tt;
+            rvm += d[0] * tt + d[1] * t2 + d[2] * (t2 * tt) + d[3] * (t2 * t2);
+        }
+        for (int k = 0; k < a.nlin; ++k)                                    // rvmodel:210-212
+            rvm += cx.lin[pl * a.nlin + k] * a.linpar[(size_t)k * a.Ne + j];
     }
-    for (int k = 0; k < a.nlin; ++k)                                        // rvmodel:210-212
-        rvm += cx.lin[pl * a.nlin + k] * a.linpar[(size_t)k * a.Ne + j];
 
     const double res = y - rvm;                                             // rvmodel:215
 #ifdef RVLL_AB_NO_LOGDET              // (measurement builds only: the normalisation term per item, as up to round 2)
@@ -737,7 +740,7 @@ __device__ __forceinline__ void tile_write_point(const LoglikeArgs& __restrict__
 // sizes and shard sizes.
 // TRACE: diagnostic build (launch_loglike_trace) — a few s_memrealtime stamps per workgroup go to a.trace, a
 // buffer nothing else reads; no stamp executes in the product kernels.
-template <int PREC, int FUSED, bool TRACE = false, int NT = kThreads, bool DYN = false>
+template <int PREC, int FUSED, bool TRACE = false, int NT = kThreads, bool DYN = false, bool EXTRAS = true>
 __device__ __forceinline__ __attribute__((flatten)) void loglike_tile(const LoglikeArgs& __restrict__ a, double* __restrict__ smem, long long p0, int npts,
                                                                       const double* cube_rows = nullptr)
 {
@@ -818,7 +821,7 @@ __device__ __forceinline__ __attribute__((flatten)) void loglike_tile(const Logl
                 if (i < cend) {
                     int pl, j;
                     item_of(r * kWave, lane, a.Ne, pl, j);
-                    contrib[i] = eval_item<PREC, false>(a, cx, pl, j);
+                    contrib[i] = eval_item<PREC, false, EXTRAS>(a, cx, pl, j);
                 }
             }
             if constexpr (TRACE) { if (tid == 0) tr[4] = __builtin_amdgcn_s_memrealtime(); }
@@ -826,7 +829,7 @@ __device__ __forceinline__ __attribute__((flatten)) void loglike_tile(const Logl
             for (int i = base + tid; i < cend; i += NT) {
                 int pl, j;
                 item_of(i - lane, lane, a.Ne, pl, j);            // i - lane = base + 64 wave + k NT: the same for the whole wave
-                contrib[i - base] = eval_item<PREC, false>(a, cx, pl, j);
+                contrib[i - base] = eval_item<PREC, false, EXTRAS>(a, cx, pl, j);
             }
             if constexpr (TRACE) { if (lane == 0) tr[2 + wave] = __builtin_amdgcn_s_memrealtime(); }
         }
@@ -838,7 +841,7 @@ __device__ __forceinline__ __attribute__((flatten)) void loglike_tile(const Logl
         if (L.nfail[0] != 0) {
             for (int i = base + tid; i < cend; i += NT) {
                 const int pl = i / a.Ne;
-                if (L.anyfail[pl]) contrib[i - base] = eval_item<PREC, true>(a, cx, pl, i - pl * a.Ne);
+                if (L.anyfail[pl]) contrib[i - base] = eval_item<PREC, true, EXTRAS>(a, cx, pl, i - pl * a.Ne);
             }
             __syncthreads();
         }
