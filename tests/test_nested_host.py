@@ -93,3 +93,69 @@ def test_fused_callback_gives_the_same_run():
     b = run_nested_slice(prior, loglike, 3, nlive=100, dlogz=0.5, seed=9,
                          prior_loglike=lambda c: (prior(c), loglike(prior(c))))
     assert a.logz == b.logz and a.ncall == b.ncall
+
+
+class _HostLive:
+    """A stand-in for GpuRVModel's resident live set (live_init / live_step / live_get / live_dead) that keeps the rows in
+    numpy arrays and walks them with a deterministic host routine: the driver's `live=` path must be the `walker=` path,
+    bit for bit, when both are fed the same walk — whatever order the driver does its bookkeeping in."""
+
+    def __init__(self, prior, loglike, walk):
+        self.prior, self.loglike, self.walk = prior, loglike, walk
+        self.calls = []
+
+    def live_init(self, cube):
+        self.u = np.array(cube)
+        self.theta = self.prior(self.u)
+        self.logl = self.loglike(self.theta)
+        self.dead_theta, self.dead_logl = [], []
+        return self.logl.copy()
+
+    def live_step(self, order, kdead, start, lstar, wrapped=None, nsteps=10, max_rounds=200, seed=0, chol=None):
+        order, start = np.asarray(order), np.asarray(start)
+        dead, alive = order[:kdead], order[kdead:]
+        assert set(start) <= set(alive) and len(start) == kdead
+        self.dead_theta.append(self.theta[dead].copy()); self.dead_logl.append(self.logl[dead].copy())
+        if chol is None:                                  # "device" whitening: this stand-in factors the same matrix
+            ua = self.u[alive]
+            d0 = ua - ua.mean(axis=0)
+            chol = np.linalg.cholesky(d0.T @ d0 / max(1, len(alive) - 1) + 1e-14 * np.eye(self.u.shape[1]))
+        self.calls.append((kdead, float(lstar), int(seed)))
+        wu, wt, wl, used = self.walk(self.u[start], self.theta[start], self.logl[start], lstar, chol, wrapped, nsteps, max_rounds, seed)
+        self.u[dead], self.theta[dead], self.logl[dead] = wu, wt, wl
+        return wl.copy(), used
+
+    def live_get(self):
+        return self.u.copy(), self.theta.copy(), self.logl.copy()
+
+    def live_dead(self):
+        return np.vstack(self.dead_theta), np.concatenate(self.dead_logl)
+
+
+@pytest.mark.parametrize("live_chol", ["device", "host"])
+def test_resident_live_set_path_is_the_walker_path(live_chol):
+    prior = lambda cube: -10.0 + 20.0 * cube
+    loglike = lambda x: -0.5 * np.sum(x * x, axis=1)
+
+    def walk(cube, theta, logl, lstar, chol, wrapped, nsteps, max_rounds, seed):
+        # a crude but deterministic constrained move: shrink towards the centre of the cube until inside logL > lstar
+        rng = np.random.default_rng(seed)
+        c = cube.copy()
+        used = 0
+        for _ in range(nsteps):
+            prop = np.clip(c + (rng.standard_normal(c.shape) @ chol.T) * 0.5, 0.0, np.nextafter(1.0, 0.0))
+            ok = loglike(prior(prop)) > lstar
+            used += len(c)
+            c[ok] = prop[ok]
+        th = prior(c)
+        return c, th, loglike(th), used
+
+    kw = dict(nlive=300, kbatch=100, nsteps=4, dlogz=0.05, max_calls=200_000, seed=9)
+    ref = run_nested_slice(prior, loglike, 3, walker=walk, **kw)
+    live = _HostLive(prior, loglike, walk)
+    got = run_nested_slice(None, None, 3, live=live, live_chol=live_chol, **kw)
+    assert got.niter == ref.niter and got.ncall == ref.ncall and got.logz == ref.logz and got.information == ref.information
+    assert np.array_equal(got.samples, ref.samples) and np.array_equal(got.logl, ref.logl) and np.array_equal(got.logwt, ref.logwt)
+    assert len(live.calls) == ref.niter // 100 and all(k == 100 for k, _, _ in live.calls)
+    with pytest.raises(ValueError):
+        run_nested_slice(None, None, 3, live=live, live_chol="elsewhere", **kw)
