@@ -1576,10 +1576,23 @@ int walk_core(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t m
         if (r) return r;
         make_fused(h, h->d_cube, h->d_theta, a);
         a->defer = nullptr;                            // deferrals are per walker here (steps_done), not per batch
+        auto window = [&](int pb) {                    // the tile's contribution window also holds 3 PB D doubles of the walk
+            int ch = std::min(h->chunk_items, std::max(rvll::kThreads, pb * h->Ne));
+            ch = std::max(ch, 3 * pb * a->D);
+            return (ch + 1) & ~1;
+        };
+        // Walker slots per workgroup: the walk's own phases cost a workgroup iteration the same whatever the number of
+        // slots, so more slots spread them thinner — as long as four workgroups still fit a compute unit's LDS.  Measured at
+        // cfg3 (profiles/r03_walk_forms.txt): 8: 1.54, 10: 1.58, 12: 1.58, 14: 1.53, 16: 1.47e8 calls/s inside the walk.
+        if (h->pb_override <= 0 && n >= 4096) {
+            a->PB = std::min(10, rvll::kMaxPointsPerBlock);
+            a->CH = window(a->PB);
+            while (a->PB > 1 && 4 * rvll::walk_lds_bytes(*a) > rvll::kCuLdsBudget) { a->PB -= 1; a->CH = window(a->PB); }
+        }
+        a->CH = window(a->PB);
         while (a->PB > 1 && (rvll::walk_lds_bytes(*a) > 60 * 1024 || (long long)a->PB * a->D > 4 * rvll::kThreads)) {
             a->PB -= 1;
-            a->CH = std::min(h->chunk_items, std::max(rvll::kThreads, a->PB * h->Ne));
-            a->CH = (a->CH + 1) & ~1;
+            a->CH = window(a->PB);
         }
         if (rvll::walk_lds_bytes(*a) > 64 * 1024 || (long long)a->PB * a->D > 4 * rvll::kThreads)
             return fail(RVLL_E_UNSUPPORTED, "%d parameters exceed the walk kernel's LDS budget", a->D);
@@ -1620,7 +1633,8 @@ int walk_core(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t m
     const char* penv = getenv("RVLL_WALK_PARTS");
     const bool two_parts = resident > 0 && K > resident * a.PB && nsteps >= 8 && !(penv && atoi(penv) == 1);
     const char* renv = getenv("RVLL_WALK_ROWS");
-    const bool rows_form = renv && atoi(renv) == 1;
+    const bool rows_form = renv && atoi(renv) >= 1 && 3LL * a.PB * a.D <= a.CH;      // (the rows kernels park their candidates in the tile's window)
+    const bool rows_cu = renv && atoi(renv) == 2;
     if (two_parts) {
         w.nsteps = std::max(1, rows_form ? nsteps / 8 : nsteps / 4);
         if (const char* e = getenv("RVLL_WALK_FIRST")) w.nsteps = std::max(1, std::min(nsteps - 1, atoi(e)));   // measurement switch
@@ -1655,21 +1669,42 @@ int walk_core(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t m
         w.step_start = h->d_walk_steps;    // every row resumes where the first part left it (read before it is rewritten)
         if (K2 > 0 && rows_form) {
             // as many workgroups as the chip holds, every one an equal share of the rows (snake deal of the sorted order,
-            // in the kernel); a share that does not fit the kernel's LDS goes in several launches, one after the other
-            const int64_t G = std::min<int64_t>((K2 + a.PB - 1) / a.PB, resident);
+            // in the kernel); a share that does not fit the kernel's LDS goes in several launches, one after the other.
+            // RVLL_WALK_ROWS=2: the CU-wide form — one 1024-thread workgroup per compute unit with as many walker slots
+            // (<= 64) as its LDS holds next to the parked rows, the tile in its CU-wide form
+            rvll::LoglikeArgs ar = a;
+            int64_t G = std::min<int64_t>((K2 + a.PB - 1) / a.PB, resident);
+            const bool cu_wide = rows_cu && slim;            // (the full-solver instantiation does not fit 128 VGPRs unspilled)
+            if (cu_wide) {
+                G = std::min<int64_t>(max_cus > 0 ? max_cus : h->n_cu, K2);
+                const int64_t rows = (K2 + G - 1) / G;
+                int slots = (int)std::min<int64_t>(rvll::kWave, rows);
+                auto fits = [&](int sl) {
+                    ar.PB = sl;
+                    ar.CH = (std::max(sl * h->Ne, 3 * sl * h->L.ndim) + 1) & ~1;
+                    return rvll::walk_rows_lds_bytes(ar, (int)rows) <= rvll::kCuLdsBudget;
+                };
+                while (slots > 1 && !fits(slots)) --slots;
+                if (!fits(slots)) return fail(RVLL_E_UNSUPPORTED, "the CU-wide walk does not fit %lld rows per compute unit", (long long)rows);
+                rc = rvll_dev_reserve(h, std::max<int64_t>(K, G * slots) + rvll::kMaxPointsPerBlock);   // the tiles' scratch rows
+                if (rc) return rc;
+                ar.theta = h->d_theta; ar.logL = h->d_logL2[0]; ar.flags = h->d_flags2[0];
+                make_fused(h, h->d_cube, h->d_theta, &ar);
+                ar.defer = nullptr;
+            }
             int64_t rmax = 1;
-            while (rmax < 4096 && rvll::walk_rows_lds_bytes(a, (int)rmax + 1) <= 60 * 1024) ++rmax;
+            const size_t budget = cu_wide ? rvll::kCuLdsBudget : (size_t)60 * 1024;
+            while (rmax < 4096 && rvll::walk_rows_lds_bytes(ar, (int)rmax + 1) <= budget) ++rmax;
             const int64_t chunk = G * rmax;
             HIP_TRY(hipMemcpyAsync(h->d_walk_order, order.data(), sizeof(int32_t) * (size_t)K2, hipMemcpyHostToDevice, st));
             for (int64_t lo = 0; lo < K2; lo += chunk) {
                 const int64_t n = std::min<int64_t>(chunk, K2 - lo);
-                // (a chunk of a multi-launch walk takes every chunk-th row of the order, so each holds all cost tiers)
                 rvll::WalkArgs wr = w;
                 wr.K = n;
                 wr.order = h->d_walk_order + lo;
-                const int64_t g = std::min<int64_t>(G, (n + a.PB - 1) / a.PB);
+                const int64_t g = std::min<int64_t>(G, (n + ar.PB - 1) / ar.PB);
                 wr.rows_per_wg = (int)((n + g - 1) / g);
-                HIP_TRY(rvll::launch_slice_walk_rows(a, wr, !slim, (int)g, st));
+                HIP_TRY(rvll::launch_slice_walk_rows(ar, wr, !slim, (int)g, cu_wide, st));
             }
             HIP_TRY(hipStreamSynchronize(st)); // `order` goes out of scope
         } else if (K2 > 0) {

@@ -71,16 +71,22 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
     const int nw = (int)min((long long)PB, w.K - w0);
     if (nw <= 0) return;
     double* wu   = smem + ((cv.total_doubles + 1) & ~1);   // [PB][D] current positions
-    double* dir  = wu + PB * D;                            // [PB][D] normals, then unit directions
-    double* lo_s = dir + PB * D;                           // [PB][D] per-coordinate chord limits of a starting move
-    double* hi_s = lo_s + PB * D;
-    double* tmin = hi_s + PB * D;                          // [PB]
+    double* dir  = wu + PB * D;                            // [PB][D] unit directions
+    double* tmin = dir + PB * D;                           // [PB]
     double* tmax = tmin + PB;
     double* slot_t = tmax + PB;                            // [PB] per tile slot: position along its walker's direction
     double* wl   = slot_t + PB;
-    double* cand = wl + PB;                                // [PB][D] per tile slot: the candidate's unit-cube row
+    // The candidates' unit-cube rows [PB][D] and the per-coordinate chord limits of a starting move (2 x [PB][D]) live in the
+    // tile's contribution window (round 3): the tile's staging step has read the candidates, and a barrier has passed,
+    // before its items write the first contribution, and nothing outside the tile needs them afterwards — an accepted
+    // candidate is recomputed from its walker's position, direction and step (the same arithmetic: the same bits).  That is
+    // 3 PB D doubles less LDS per workgroup: twelve walker slots now fit four workgroups per compute unit, and the walk's own
+    // phases — paid per workgroup iteration whatever the number of slots — are spread over half as many again.
+    double* cand = smem + cv.contrib;
+    double* lo_s = cand + PB * D;
+    double* hi_s = lo_s + PB * D;
     const bool chol_in_lds = D <= kWalkCholLds;
-    double* chol_s = cand + PB * D;                        // [D][D] the whitening factor, when it is small enough to stage
+    double* chol_s = wl + PB;                              // [D][D] the whitening factor, when it is small enough to stage
     int* act     = reinterpret_cast<int*>(chol_s + (chol_in_lds ? D * D : 0));   // [2][PB] walkers with moves left (local index),
                                                             // compacted; the list of the next iteration is written while this one's is read
     int* state   = act + 2 * PB;                              // [PB] 0: needs a new direction, 1: in a move, 2: accepted just now, 3: deferred
@@ -321,7 +327,9 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
             const int ai = i / D, k = i - ai * D, pl = act[ai];
             const int sl = acc_slot[pl];
             if (sl < 0) continue;
-            wu[pl * D + k] = cand[sl * D + k];
+            double c = wu[pl * D + k] + slot_t[sl] * dir[pl * D + k];      // the accepted candidate, as it was made above
+            if (wrapped_s[k]) c -= floor(c);
+            wu[pl * D + k] = fmin(fmax(c, 0.), one_below);
             w.theta[(long long)acc_g[pl] * D + k] = L.theta_s[sl * D + k];
         }
         if (tid == kThreads - 1) {
@@ -378,10 +386,19 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
 // does.  The random-number counters name the row, so which slot walks which move of which row changes nothing: end points,
 // log-L, theta and ncalls are those of slice_walk_kernel, bit for bit (tests/test_gpu_walk.py).
 constexpr int kRowSlack = 2;
-template <int PREC, bool FAT>
-__global__ __launch_bounds__(kThreads, FAT ? 2 : RVLL_WALK_WAVES) __attribute__((flatten))
+// NT = 256: four such workgroups per compute unit, a.PB (8) walker slots each, the tile in its 256-thread form.
+// NT = 1024 (the CU-wide form, round 3): ONE workgroup fills the compute unit, up to 64 walker slots, the tile in its
+// CU-wide form (every candidate's contributions resident in LDS, wave rounds from the ticket counter).  A candidate of
+// the 8-slot form costs 2600 vector instructions against the batch tile's 1990 (profiles/r03_walk_forms.txt): the prior
+// stage runs every prior kind in every wave at 8 points a tile, and the walk's own phases (directions, chords,
+// candidates, accept, bookkeeping) are paid per workgroup iteration whatever the number of slots.  With 48 - 64 slots
+// under one set of phases the stage's waves each run ONE kind, and the phases are amortised over six to eight times the
+// candidates.
+template <int PREC, bool FAT, int NT>
+__global__ __launch_bounds__(NT, NT == kCuThreads ? 1 : (FAT ? 2 : RVLL_WALK_WAVES)) __attribute__((flatten))
 void slice_walk_rows_kernel(const LoglikeArgs a, const WalkArgs w)
 {
+    constexpr bool DYN = NT == kCuThreads;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const Carve cv = carve(a.PB, a.D, a.Np, a.Ni, a.nlin, a.CH);
     const int D = a.D, PB = a.PB, tid = threadIdx.x, R = w.rows_per_wg, G = gridDim.x;
@@ -389,15 +406,19 @@ void slice_walk_rows_kernel(const LoglikeArgs a, const WalkArgs w)
     const int nw = PB;                                        // tile slots
     double* wu   = smem + ((cv.total_doubles + 1) & ~1);   // [PB][D] current positions of the walkers in the slots
     double* dir  = wu + PB * D;
-    double* lo_s = dir + PB * D;
-    double* hi_s = lo_s + PB * D;
-    double* tmin = hi_s + PB * D;
+    double* tmin = dir + PB * D;
     double* tmax = tmin + PB;
     double* slot_t = tmax + PB;
     double* wl   = slot_t + PB;
-    double* cand = wl + PB;
+    // The candidates' unit-cube rows and the per-coordinate chord limits live in the tile's contribution window: the tile's
+    // staging step has read the candidates (and a barrier has passed) before its items write the first contribution, and
+    // nothing outside the tile needs them afterwards — an accepted candidate is recomputed from its walker's position,
+    // direction and step (the same arithmetic: the same bits).  3 PB D doubles of a window of a.CH (host-checked).
+    double* cand = smem + cv.contrib;
+    double* lo_s = cand + PB * D;
+    double* hi_s = lo_s + PB * D;
     const bool chol_in_lds = D <= kWalkCholLds;
-    double* chol_s = cand + PB * D;
+    double* chol_s = wl + PB;
     double* ru   = chol_s + (chol_in_lds ? D * D : 0);      // [R][D] parked rows: position ...
     double* rl   = ru + R * D;                              // [R]    ... log-L ...
     int* act     = reinterpret_cast<int*>(rl + R);
@@ -427,7 +448,7 @@ void slice_walk_rows_kernel(const LoglikeArgs a, const WalkArgs w)
     const double one_below = 0.99999999999999988898;
 
     auto row_at = [&](long long k) -> int { return w.order ? w.order[k] : (int)k; };
-    for (int r = tid; r < R; r += kThreads) {
+    for (int r = tid; r < R; r += NT) {
         const long long pos = (long long)r * G + ((r & 1) ? G - 1 - (int)blockIdx.x : (int)blockIdx.x);    // snake deal
         const int g = pos < w.K ? row_at(pos) : -1;
         rrow[r] = g;
@@ -437,13 +458,13 @@ void slice_walk_rows_kernel(const LoglikeArgs a, const WalkArgs w)
         rstep[r] = ss;
     }
     __syncthreads();
-    for (int i = tid; i < R * D; i += kThreads) { const int g = rrow[i / D]; ru[i] = g >= 0 ? w.u[(long long)g * D + i % D] : 0.; }
-    if (chol_in_lds) for (int i = tid; i < D * D; i += kThreads) chol_s[i] = w.chol[i];
-    for (int i = tid; i < D; i += kThreads) wrapped_s[i] = w.wrapped[i];
-    for (int i = tid; i < PB; i += kThreads) { state[i] = 0; round_of[i] = 0; srow[i] = -1; park[i] = -1; fetch[i] = -1; step_of[i] = 0; turn[i] = 0; used_of[i] = 0; }
+    for (int i = tid; i < R * D; i += NT) { const int g = rrow[i / D]; ru[i] = g >= 0 ? w.u[(long long)g * D + i % D] : 0.; }
+    if (chol_in_lds) for (int i = tid; i < D * D; i += NT) chol_s[i] = w.chol[i];
+    for (int i = tid; i < D; i += NT) wrapped_s[i] = w.wrapped[i];
+    for (int i = tid; i < PB; i += NT) { state[i] = 0; round_of[i] = 0; srow[i] = -1; park[i] = -1; fetch[i] = -1; step_of[i] = 0; turn[i] = 0; used_of[i] = 0; }
     const int lane = tid & (kWave - 1);
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
-    if (tid >= kThreads - kWave) {                          // the ring starts with every row that has moves left, in row order
+    if (tid >= NT - kWave) {                          // the ring starts with every row that has moves left, in row order
         int count = 0;
         for (int r0 = 0; r0 < R; r0 += kWave) {
             const int r = r0 + lane;
@@ -534,7 +555,7 @@ void slice_walk_rows_kernel(const LoglikeArgs a, const WalkArgs w)
         }
     };
     int* const act0 = act;
-    if (tid >= kThreads - kWave) bookkeep(act);             // every slot is free: they take the first rows of the ring
+    if (tid >= NT - kWave) bookkeep(act);             // every slot is free: they take the first rows of the ring
 #ifdef RVLL_AB_STAGGER
     // The workgroups of this form all start together and do the same work per iteration: the four that share a compute
     // unit would reach their tiles together and their serial phases together.  A start offset (0 .. 3 quarters of an
@@ -558,7 +579,7 @@ void slice_walk_rows_kernel(const LoglikeArgs a, const WalkArgs w)
     for (long long iter = 0; iter < max_iters; ++iter) {
         const int nact = nact_s[0], nslots = nact_s[1], nswap = nact_s[2];
         if (nswap) {                                        // walkers change places with parked rows (LDS to LDS)
-            for (int i = tid; i < PB * D; i += kThreads) {
+            for (int i = tid; i < PB * D; i += NT) {
                 const int pl = i / D, k = i - pl * D, st = park[pl], ld = fetch[pl];
                 if (st >= 0) { ru[st * D + k] = wu[i]; if (k == 0) rl[st] = wl[pl]; }
                 if (ld >= 0) { wu[i] = ru[ld * D + k]; if (k == 0) { wl[pl] = rl[ld]; step_of[pl] = rstep[ld]; } }
@@ -569,7 +590,7 @@ void slice_walk_rows_kernel(const LoglikeArgs a, const WalkArgs w)
         act = act0 + (iter & 1) * PB;
         int* const act_next = act0 + ((iter + 1) & 1) * PB;
         const int nstart = nact_s[3];                       // the walkers that start a move, packed (see slice_walk_kernel)
-        for (int i = tid; i < nstart * D; i += kThreads) {
+        for (int i = tid; i < nstart * D; i += NT) {
             const int pl = starts[i / D], k = i % D;
             const int g = rrow[srow[pl]];
             const unsigned long long wid = (unsigned long long)(w.walker_base + (w.walker_id ? (long long)w.walker_id[g] : (long long)g));
@@ -577,14 +598,14 @@ void slice_walk_rows_kernel(const LoglikeArgs a, const WalkArgs w)
             lo_s[pl * D + k] = walk_normal(w.seed, ctr);
         }
         __syncthreads();
-        for (int i = tid; i < nstart * D; i += kThreads) {
+        for (int i = tid; i < nstart * D; i += NT) {
             const int pl = starts[i / D], k = i % D;
             double acc = 0.;
             for (int j = 0; j <= k; ++j) acc += chol[k * D + j] * lo_s[pl * D + j];
             cand[pl * D + k] = acc;
         }
         __syncthreads();
-        for (int i = tid; i < nstart * D; i += kThreads) {
+        for (int i = tid; i < nstart * D; i += NT) {
             const int pl = starts[i / D], k = i % D;
             double n2 = 0.;
             for (int j = 0; j < D; ++j) n2 += cand[pl * D + j] * cand[pl * D + j];
@@ -604,7 +625,7 @@ void slice_walk_rows_kernel(const LoglikeArgs a, const WalkArgs w)
         }
         __syncthreads();
         WALK_STAMP(0);
-        for (int ai = tid; ai < nact; ai += kThreads) {
+        for (int ai = tid; ai < nact; ai += NT) {
             const int pl = act[ai];
             if (state[pl] == 0) {
                 double lo = -INFINITY, hi = INFINITY;
@@ -625,7 +646,7 @@ void slice_walk_rows_kernel(const LoglikeArgs a, const WalkArgs w)
             }
         }
         __syncthreads();
-        for (int i = tid; i < nslots * D; i += kThreads) {
+        for (int i = tid; i < nslots * D; i += NT) {
             const int sl = i / D, k = i - sl * D, pl = slot_pl[sl];
             double c = wu[pl * D + k] + slot_t[sl] * dir[pl * D + k];
             if (wrapped_s[k]) c -= floor(c);
@@ -633,11 +654,11 @@ void slice_walk_rows_kernel(const LoglikeArgs a, const WalkArgs w)
         }
         __syncthreads();
         WALK_STAMP(1);
-        loglike_tile<PREC, FAT ? kFusedFull : kFusedSlim>(a, smem, w0, nslots, cand);
+        loglike_tile<PREC, FAT ? kFusedFull : kFusedSlim, false, NT, DYN>(a, smem, w0, nslots, cand);
         __builtin_amdgcn_s_setprio(3);
         __syncthreads();
         WALK_STAMP(2);
-        for (int ai = tid; ai < nact; ai += kThreads) {
+        for (int ai = tid; ai < nact; ai += NT) {
             const int pl = act[ai];
             const int first = first_of[pl], S = nsp_of[pl];
             int used = 0;
@@ -661,14 +682,16 @@ void slice_walk_rows_kernel(const LoglikeArgs a, const WalkArgs w)
             used_of[pl] = used;
         }
         __syncthreads();
-        for (int i = tid; i < nact * D; i += kThreads) {
+        for (int i = tid; i < nact * D; i += NT) {
             const int ai = i / D, k = i - ai * D, pl = act[ai];
             const int sl = acc_slot[pl];
             if (sl < 0) continue;
-            wu[pl * D + k] = cand[sl * D + k];
+            double c = wu[pl * D + k] + slot_t[sl] * dir[pl * D + k];      // the accepted candidate, as it was made above
+            if (wrapped_s[k]) c -= floor(c);
+            wu[pl * D + k] = fmin(fmax(c, 0.), one_below);
             w.theta[(long long)acc_g[pl] * D + k] = L.theta_s[sl * D + k];
         }
-        if (tid >= kThreads - kWave) {
+        if (tid >= NT - kWave) {
             if (lane == 0) slots += (unsigned long long)nslots;
             bookkeep(act_next);
         }
@@ -676,16 +699,16 @@ void slice_walk_rows_kernel(const LoglikeArgs a, const WalkArgs w)
         WALK_STAMP(3);
     }
     // rows go home
-    for (int i = tid; i < R * D; i += kThreads) { const int g = rrow[i / D]; if (g >= 0) w.u[(long long)g * D + i % D] = ru[i]; }
-    for (int r = tid; r < R; r += kThreads) {
+    for (int i = tid; i < R * D; i += NT) { const int g = rrow[i / D]; if (g >= 0) w.u[(long long)g * D + i % D] = ru[i]; }
+    for (int r = tid; r < R; r += NT) {
         const int g = rrow[r];
         if (g < 0) continue;
         w.logl[g] = rl[r];
         if (w.steps_done) w.steps_done[g] = rstep[r];
         if (w.cost) w.cost[g] = rcost[r];
     }
-    if (tid >= kThreads - kWave && calls) atomicAdd(w.ncalls, (unsigned long long)calls);   // (two's complement: a negative share adds up right)
-    if (tid >= kThreads - kWave && slots && w.nslots) atomicAdd(w.nslots, slots);
+    if (tid >= NT - kWave && calls) atomicAdd(w.ncalls, (unsigned long long)calls);   // (two's complement: a negative share adds up right)
+    if (tid >= NT - kWave && slots && w.nslots) atomicAdd(w.nslots, slots);
 #ifdef RVLL_WALK_TRACE
     if (tid == 0 && w.nslots) {
         for (int k = 0; k < 4; ++k) atomicAdd(w.nslots + 1 + k, ph[k]);
@@ -701,14 +724,14 @@ void slice_walk_rows_kernel(const LoglikeArgs a, const WalkArgs w)
 size_t walk_lds_bytes(const LoglikeArgs& a)
 {
     const size_t base = (loglike_lds_bytes(a) + 15) & ~(size_t)15;
-    return base + sizeof(double) * ((size_t)5 * a.PB * a.D + 4 * a.PB + (a.D <= kWalkCholLds ? a.D * a.D : 0)) +
+    return base + sizeof(double) * ((size_t)2 * a.PB * a.D + 4 * a.PB + (a.D <= kWalkCholLds ? a.D * a.D : 0)) +
            sizeof(int) * (16 * a.PB + 4 + a.D) + 16;
 }
 
 size_t walk_rows_lds_bytes(const LoglikeArgs& a, int R)
 {
     const size_t base = (loglike_lds_bytes(a) + 15) & ~(size_t)15;
-    return base + sizeof(double) * ((size_t)5 * a.PB * a.D + 4 * a.PB + (a.D <= kWalkCholLds ? a.D * a.D : 0) + (size_t)R * a.D + R) +
+    return base + sizeof(double) * ((size_t)2 * a.PB * a.D + 4 * a.PB + (a.D <= kWalkCholLds ? a.D * a.D : 0) + (size_t)R * a.D + R) +
            sizeof(int) * (16 * a.PB + 6 + a.D + 4 * (size_t)R) + 16;
 }
 
@@ -734,7 +757,8 @@ hipError_t launch_slice_walk(const LoglikeArgs& a, const WalkArgs& w, bool fat, 
 {
     if (w.K <= 0 || w.nsteps <= 0) return hipSuccess;
     if (!a.cube || !a.theta_out || !a.priors || !a.flags || a.PB * a.D > 4 * kThreads || w.nsteps >= (1 << 18) ||
-        w.max_rounds < 1 || w.max_rounds > 4096 || a.D > 4096 || (!fat && !w.steps_done) || w.spec_max < 1)
+        w.max_rounds < 1 || w.max_rounds > 4096 || a.D > 4096 || (!fat && !w.steps_done) || w.spec_max < 1 ||
+        3LL * a.PB * a.D > a.CH)                            // the candidates and chord limits borrow the tile's window
         return hipErrorInvalidValue;
     const size_t lds = walk_lds_bytes(a);
     if (lds > 64 * 1024 || !w.queue) return hipErrorInvalidValue;
@@ -764,25 +788,44 @@ hipError_t launch_slice_walk(const LoglikeArgs& a, const WalkArgs& w, bool fat, 
     return hipGetLastError();
 }
 
-hipError_t launch_slice_walk_rows(const LoglikeArgs& a, const WalkArgs& w, bool fat, int nblocks, hipStream_t stream)
+hipError_t launch_slice_walk_rows(const LoglikeArgs& a, const WalkArgs& w, bool fat, int nblocks, bool cu_wide, hipStream_t stream)
 {
     if (w.K <= 0 || w.nsteps <= 0) return hipSuccess;
-    if (!a.cube || !a.theta_out || !a.priors || !a.flags || a.PB * a.D > 4 * kThreads || w.nsteps >= (1 << 18) ||
+    const int nt = cu_wide ? kCuThreads : kThreads;
+    if (!a.cube || !a.theta_out || !a.priors || !a.flags || a.PB * a.D > 4 * nt || a.PB > kWave || w.nsteps >= (1 << 18) ||
         w.max_rounds < 1 || w.max_rounds > 4096 || a.D > 4096 || (!fat && !w.steps_done) || w.spec_max < 1 ||
-        nblocks < 1 || w.rows_per_wg < 1 || (long long)nblocks * w.rows_per_wg < w.K)
+        nblocks < 1 || w.rows_per_wg < 1 || (long long)nblocks * w.rows_per_wg < w.K || 3LL * a.PB * a.D > a.CH ||
+        (cu_wide && (long long)a.CH < (long long)a.PB * a.Ne))
         return hipErrorInvalidValue;
     const size_t lds = walk_rows_lds_bytes(a, w.rows_per_wg);
-    if (lds > 64 * 1024) return hipErrorInvalidValue;
-    const dim3 grid((unsigned)nblocks), block(kThreads);
-#define RVLL_WALK(PREC)                                                                                              \
-    if (fat) hipLaunchKernelGGL((slice_walk_rows_kernel<PREC, true>), grid, block, lds, stream, a, w);              \
-    else     hipLaunchKernelGGL((slice_walk_rows_kernel<PREC, false>), grid, block, lds, stream, a, w)
+    if (lds > (cu_wide ? kCuLdsBudget : (size_t)64 * 1024)) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)nblocks), block(nt);
+    if (cu_wide) {
+        static bool attr_set_dev[64] = {};                      // raise the dynamic-LDS limit of every instance once per device
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (!attr_set_dev[dev & 63]) {
+            const int lim = (int)kCuLdsBudget;
+            hipError_t e = hipSuccess;
+#define RVLL_WALK_ATTR(PREC, FATV) if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(slice_walk_rows_kernel<PREC, FATV, kCuThreads>), hipFuncAttributeMaxDynamicSharedMemorySize, lim)
+            RVLL_WALK_ATTR(RVLL_PREC_FP64, false); RVLL_WALK_ATTR(RVLL_PREC_MIXED, false); RVLL_WALK_ATTR(RVLL_PREC_FP32, false);
+            RVLL_WALK_ATTR(RVLL_PREC_FP64, true);  RVLL_WALK_ATTR(RVLL_PREC_MIXED, true);  RVLL_WALK_ATTR(RVLL_PREC_FP32, true);
+#undef RVLL_WALK_ATTR
+            if (e != hipSuccess) return e;
+            attr_set_dev[dev & 63] = true;
+        }
+    }
+#define RVLL_WALK_NT(PREC, NTV)                                                                                      \
+    if (fat) hipLaunchKernelGGL((slice_walk_rows_kernel<PREC, true, NTV>), grid, block, lds, stream, a, w);         \
+    else     hipLaunchKernelGGL((slice_walk_rows_kernel<PREC, false, NTV>), grid, block, lds, stream, a, w)
+#define RVLL_WALK(PREC) do { if (cu_wide) { RVLL_WALK_NT(PREC, kCuThreads); } else { RVLL_WALK_NT(PREC, kThreads); } } while (0)
     switch (a.precision) {
     case RVLL_PREC_MIXED: RVLL_WALK(RVLL_PREC_MIXED); break;
     case RVLL_PREC_FP32:  RVLL_WALK(RVLL_PREC_FP32); break;
     default:              RVLL_WALK(RVLL_PREC_FP64); break;
     }
 #undef RVLL_WALK
+#undef RVLL_WALK_NT
     return hipGetLastError();
 }
 

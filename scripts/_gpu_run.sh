@@ -1,7 +1,6 @@
 set -o pipefail
-timeout -k 10 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -2
-for v in full nologdet full nologdet; do
-  if [ "$v" = full ]; then lib=evidence_amd/librvll.so; else lib=evidence_amd/diag/librvll_$v.so; fi
-  RVLL_LIBRARY=$PWD/$lib python scripts/scalar_latency_ab.py $v
-done
-python bench.py --no-cpu --no-extras | python scripts/show_bench_keys.py /dev/stdin | cut -c1-140
+mkdir -p gpurun_out/r4d
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/r4d/gputests.log 2>&1; rc=$?; echo "gpu tests rc=$rc"; tail -3 gpurun_out/r4d/gputests.log | cut -c1-200
+python3 bench.py > gpurun_out/r4d/bench_default.json 2> gpurun_out/r4d/bench_default.err; echo "bench default rc=$?"
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r4d/bench_driver_args.json 2> gpurun_out/r4d/bench_driver_args.err; echo "bench driver rc=$?"
+python3 scripts/show_bench_keys.py gpurun_out/r4d/bench_default.json gpurun_out/r4d/bench_driver_args.json | grep -E "value|nested" | cut -c1-420
