@@ -1634,7 +1634,7 @@ int walk_core(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t m
     const bool two_parts = resident > 0 && K > resident * a.PB && nsteps >= 8 && !(penv && atoi(penv) == 1);
     const char* renv = getenv("RVLL_WALK_ROWS");
     const bool rows_form = renv && atoi(renv) >= 1 && 3LL * a.PB * a.D <= a.CH;      // (the rows kernels park their candidates in the tile's window)
-    const bool rows_cu = renv && atoi(renv) == 2;
+    const int rows_wide = renv && atoi(renv) == 2 ? rvll::kCuThreads : renv && atoi(renv) == 3 ? 512 : 0;   // 2: one 1024-thread workgroup per CU, 3: two of 512
     if (two_parts) {
         w.nsteps = std::max(1, rows_form ? nsteps / 8 : nsteps / 4);
         if (const char* e = getenv("RVLL_WALK_FIRST")) w.nsteps = std::max(1, std::min(nsteps - 1, atoi(e)));   // measurement switch
@@ -1671,21 +1671,24 @@ int walk_core(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t m
             // as many workgroups as the chip holds, every one an equal share of the rows (snake deal of the sorted order,
             // in the kernel); a share that does not fit the kernel's LDS goes in several launches, one after the other.
             // RVLL_WALK_ROWS=2: the CU-wide form — one 1024-thread workgroup per compute unit with as many walker slots
-            // (<= 64) as its LDS holds next to the parked rows, the tile in its CU-wide form
+            // (<= 64) as its LDS holds next to the parked rows, the tile in its CU-wide form; 3: two 512-thread workgroups
             rvll::LoglikeArgs ar = a;
             int64_t G = std::min<int64_t>((K2 + a.PB - 1) / a.PB, resident);
-            const bool cu_wide = rows_cu && slim;            // (the full-solver instantiation does not fit 128 VGPRs unspilled)
+            // (the wide forms exist for the slim stage only: the full-solver instantiation does not fit 128 VGPRs unspilled)
+            const int nt = (rows_wide && slim) ? rows_wide : rvll::kThreads;
+            const bool cu_wide = nt != rvll::kThreads;
+            const size_t wide_budget = nt == rvll::kCuThreads ? rvll::kCuLdsBudget : rvll::kCuLdsBudget / 2;
             if (cu_wide) {
-                G = std::min<int64_t>(max_cus > 0 ? max_cus : h->n_cu, K2);
+                G = std::min<int64_t>((int64_t)(max_cus > 0 ? max_cus : h->n_cu) * (rvll::kCuThreads / nt), K2);
                 const int64_t rows = (K2 + G - 1) / G;
                 int slots = (int)std::min<int64_t>(rvll::kWave, rows);
                 auto fits = [&](int sl) {
                     ar.PB = sl;
                     ar.CH = (std::max(sl * h->Ne, 3 * sl * h->L.ndim) + 1) & ~1;
-                    return rvll::walk_rows_lds_bytes(ar, (int)rows) <= rvll::kCuLdsBudget;
+                    return rvll::walk_rows_lds_bytes(ar, (int)rows) <= wide_budget;
                 };
                 while (slots > 1 && !fits(slots)) --slots;
-                if (!fits(slots)) return fail(RVLL_E_UNSUPPORTED, "the CU-wide walk does not fit %lld rows per compute unit", (long long)rows);
+                if (!fits(slots)) return fail(RVLL_E_UNSUPPORTED, "the wide walk does not fit %lld rows per workgroup", (long long)rows);
                 rc = rvll_dev_reserve(h, std::max<int64_t>(K, G * slots) + rvll::kMaxPointsPerBlock);   // the tiles' scratch rows
                 if (rc) return rc;
                 ar.theta = h->d_theta; ar.logL = h->d_logL2[0]; ar.flags = h->d_flags2[0];
@@ -1693,7 +1696,7 @@ int walk_core(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t m
                 ar.defer = nullptr;
             }
             int64_t rmax = 1;
-            const size_t budget = cu_wide ? rvll::kCuLdsBudget : (size_t)60 * 1024;
+            const size_t budget = cu_wide ? wide_budget : (size_t)60 * 1024;
             while (rmax < 4096 && rvll::walk_rows_lds_bytes(ar, (int)rmax + 1) <= budget) ++rmax;
             const int64_t chunk = G * rmax;
             HIP_TRY(hipMemcpyAsync(h->d_walk_order, order.data(), sizeof(int32_t) * (size_t)K2, hipMemcpyHostToDevice, st));
@@ -1704,7 +1707,7 @@ int walk_core(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t m
                 wr.order = h->d_walk_order + lo;
                 const int64_t g = std::min<int64_t>(G, (n + ar.PB - 1) / ar.PB);
                 wr.rows_per_wg = (int)((n + g - 1) / g);
-                HIP_TRY(rvll::launch_slice_walk_rows(ar, wr, !slim, (int)g, cu_wide, st));
+                HIP_TRY(rvll::launch_slice_walk_rows(ar, wr, !slim, (int)g, nt, st));
             }
             HIP_TRY(hipStreamSynchronize(st)); // `order` goes out of scope
         } else if (K2 > 0) {

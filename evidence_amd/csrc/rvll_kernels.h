@@ -122,8 +122,9 @@ long long slice_walk_resident_blocks(const LoglikeArgs& a, bool fat, int cus);
 // k mod nblocks, every other tier reversed), park them in LDS and interleave them over their a.PB walker slots at move
 // boundaries, so that all rows end together.  Same results as launch_slice_walk, bit for bit.  No queue, no w.cost needed.
 size_t walk_rows_lds_bytes(const LoglikeArgs& a, int rows_per_wg);
-// cu_wide: one 1024-thread workgroup per compute unit (a.PB <= 64 slots, a.CH >= a.PB * a.Ne), else 256-thread workgroups
-hipError_t launch_slice_walk_rows(const LoglikeArgs& a, const WalkArgs& w, bool fat, int nblocks, bool cu_wide, hipStream_t stream);
+// nt: threads per workgroup — 256 (four workgroups per compute unit), 512 (two) or 1024 (one; a.PB <= 64 slots and, for the two wide
+// forms, a.CH >= a.PB * a.Ne: the tile draws wave rounds from its ticket counter); the wide forms exist for the slim stage only
+hipError_t launch_slice_walk_rows(const LoglikeArgs& a, const WalkArgs& w, bool fat, int nblocks, int nt, hipStream_t stream);
 
 // ---- device-resident live set (rvll_live.hip): row gather / scatter by index; mean and covariance of a subset of rows
 hipError_t launch_gather_rows(const double* src, const int32_t* idx, long long n, int width, double* dst, hipStream_t st);

@@ -394,11 +394,13 @@ constexpr int kRowSlack = 2;
 // candidates, accept, bookkeeping) are paid per workgroup iteration whatever the number of slots.  With 48 - 64 slots
 // under one set of phases the stage's waves each run ONE kind, and the phases are amortised over six to eight times the
 // candidates.
+// NT = 512: two workgroups per compute unit, about 30 slots each, tickets as in the CU-wide form — one's phases under the
+// other's tile.
 template <int PREC, bool FAT, int NT>
-__global__ __launch_bounds__(NT, NT == kCuThreads ? 1 : (FAT ? 2 : RVLL_WALK_WAVES)) __attribute__((flatten))
+__global__ __launch_bounds__(NT, NT == kCuThreads ? 1 : NT == 512 ? 4 : (FAT ? 2 : RVLL_WALK_WAVES)) __attribute__((flatten))
 void slice_walk_rows_kernel(const LoglikeArgs a, const WalkArgs w)
 {
-    constexpr bool DYN = NT == kCuThreads;
+    constexpr bool DYN = NT != kThreads;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const Carve cv = carve(a.PB, a.D, a.Np, a.Ni, a.nlin, a.CH);
     const int D = a.D, PB = a.PB, tid = threadIdx.x, R = w.rows_per_wg, G = gridDim.x;
@@ -788,44 +790,47 @@ hipError_t launch_slice_walk(const LoglikeArgs& a, const WalkArgs& w, bool fat, 
     return hipGetLastError();
 }
 
-hipError_t launch_slice_walk_rows(const LoglikeArgs& a, const WalkArgs& w, bool fat, int nblocks, bool cu_wide, hipStream_t stream)
+hipError_t launch_slice_walk_rows(const LoglikeArgs& a, const WalkArgs& w, bool fat, int nblocks, int nt, hipStream_t stream)
 {
     if (w.K <= 0 || w.nsteps <= 0) return hipSuccess;
-    const int nt = cu_wide ? kCuThreads : kThreads;
-    if (!a.cube || !a.theta_out || !a.priors || !a.flags || a.PB * a.D > 4 * nt || a.PB > kWave || w.nsteps >= (1 << 18) ||
+    const bool wide = nt != kThreads;
+    if ((nt != kThreads && nt != 512 && nt != kCuThreads) || (wide && fat) ||
+        !a.cube || !a.theta_out || !a.priors || !a.flags || a.PB * a.D > 4 * nt || a.PB > kWave || w.nsteps >= (1 << 18) ||
         w.max_rounds < 1 || w.max_rounds > 4096 || a.D > 4096 || (!fat && !w.steps_done) || w.spec_max < 1 ||
         nblocks < 1 || w.rows_per_wg < 1 || (long long)nblocks * w.rows_per_wg < w.K || 3LL * a.PB * a.D > a.CH ||
-        (cu_wide && (long long)a.CH < (long long)a.PB * a.Ne))
+        (wide && (long long)a.CH < (long long)a.PB * a.Ne))
         return hipErrorInvalidValue;
     const size_t lds = walk_rows_lds_bytes(a, w.rows_per_wg);
-    if (lds > (cu_wide ? kCuLdsBudget : (size_t)64 * 1024)) return hipErrorInvalidValue;
+    const size_t budget = nt == kCuThreads ? kCuLdsBudget : nt == 512 ? kCuLdsBudget / 2 : (size_t)64 * 1024;
+    if (lds > budget) return hipErrorInvalidValue;
     const dim3 grid((unsigned)nblocks), block(nt);
-    if (cu_wide) {
+    if (wide) {
         static bool attr_set_dev[64] = {};                      // raise the dynamic-LDS limit of every instance once per device
         int dev = 0;
         (void)hipGetDevice(&dev);
         if (!attr_set_dev[dev & 63]) {
-            const int lim = (int)kCuLdsBudget;
             hipError_t e = hipSuccess;
-#define RVLL_WALK_ATTR(PREC, FATV) if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(slice_walk_rows_kernel<PREC, FATV, kCuThreads>), hipFuncAttributeMaxDynamicSharedMemorySize, lim)
-            RVLL_WALK_ATTR(RVLL_PREC_FP64, false); RVLL_WALK_ATTR(RVLL_PREC_MIXED, false); RVLL_WALK_ATTR(RVLL_PREC_FP32, false);
-            RVLL_WALK_ATTR(RVLL_PREC_FP64, true);  RVLL_WALK_ATTR(RVLL_PREC_MIXED, true);  RVLL_WALK_ATTR(RVLL_PREC_FP32, true);
+#define RVLL_WALK_ATTR(PREC, NTV, LIM) if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(slice_walk_rows_kernel<PREC, false, NTV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(LIM))
+            RVLL_WALK_ATTR(RVLL_PREC_FP64, kCuThreads, kCuLdsBudget); RVLL_WALK_ATTR(RVLL_PREC_MIXED, kCuThreads, kCuLdsBudget); RVLL_WALK_ATTR(RVLL_PREC_FP32, kCuThreads, kCuLdsBudget);
+            RVLL_WALK_ATTR(RVLL_PREC_FP64, 512, kCuLdsBudget / 2); RVLL_WALK_ATTR(RVLL_PREC_MIXED, 512, kCuLdsBudget / 2); RVLL_WALK_ATTR(RVLL_PREC_FP32, 512, kCuLdsBudget / 2);
 #undef RVLL_WALK_ATTR
             if (e != hipSuccess) return e;
             attr_set_dev[dev & 63] = true;
         }
     }
-#define RVLL_WALK_NT(PREC, NTV)                                                                                      \
-    if (fat) hipLaunchKernelGGL((slice_walk_rows_kernel<PREC, true, NTV>), grid, block, lds, stream, a, w);         \
-    else     hipLaunchKernelGGL((slice_walk_rows_kernel<PREC, false, NTV>), grid, block, lds, stream, a, w)
-#define RVLL_WALK(PREC) do { if (cu_wide) { RVLL_WALK_NT(PREC, kCuThreads); } else { RVLL_WALK_NT(PREC, kThreads); } } while (0)
+#define RVLL_WALK(PREC)                                                                                              \
+    do {                                                                                                             \
+        if (nt == kCuThreads)  hipLaunchKernelGGL((slice_walk_rows_kernel<PREC, false, kCuThreads>), grid, block, lds, stream, a, w); \
+        else if (nt == 512)    hipLaunchKernelGGL((slice_walk_rows_kernel<PREC, false, 512>), grid, block, lds, stream, a, w);        \
+        else if (fat)          hipLaunchKernelGGL((slice_walk_rows_kernel<PREC, true, kThreads>), grid, block, lds, stream, a, w);    \
+        else                   hipLaunchKernelGGL((slice_walk_rows_kernel<PREC, false, kThreads>), grid, block, lds, stream, a, w);   \
+    } while (0)
     switch (a.precision) {
     case RVLL_PREC_MIXED: RVLL_WALK(RVLL_PREC_MIXED); break;
     case RVLL_PREC_FP32:  RVLL_WALK(RVLL_PREC_FP32); break;
     default:              RVLL_WALK(RVLL_PREC_FP64); break;
     }
 #undef RVLL_WALK
-#undef RVLL_WALK_NT
     return hipGetLastError();
 }
 

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Bias check of the nested sampler with the walk driven from the host and on the device: a 4-D Gaussian
+"""Bias check of the nested sampler with the walk driven from the host, on the device, and with the live set resident there: a 4-D Gaussian
 likelihood built from the RV model itself (four instruments, one unit-variance datum each, free offsets,
 Uniform(-10, 10) priors: ln Z = -4 ln 20), many seeds each.  Run on the GPU box."""
 import os, sys, time
@@ -20,5 +20,6 @@ with GpuRVModel({}, table, list(pri), priordict=pri) as m:
         kw = dict(nlive=nlive, kbatch=kb, dlogz=0.01, max_calls=100_000_000, nsteps=12)
         host = [run_nested_slice(prior, loglike, 4, seed=s, prior_loglike=m.prior_loglike_batch, **kw).logz for s in range(1, 17)]
         dev = [run_nested_slice(prior, loglike, 4, seed=s, walker=m.slice_walk, **kw).logz for s in range(1, 33)]
-        for name, v in (("host", host), ("dev ", dev)):
+        live = [run_nested_slice(None, None, 4, seed=s, live=m, **kw).logz for s in range(1, 33)]     # live set + whitening on the device
+        for name, v in (("host", host), ("dev ", dev), ("live", live)):
             print(f"nlive={nlive} kbatch={kb} {name}: mean-truth {np.mean(v) - truth:+.4f} +- {np.std(v) / np.sqrt(len(v)):.4f} (sd {np.std(v):.3f}, n={len(v)})", flush=True)

@@ -265,13 +265,13 @@ def test_rows_form_of_the_second_part_is_the_queue_walk(gpu_required, monkeypatc
             for umax in (30.0, 1.0):
                 m.set_slim_table_range(umax)
                 runs = {}
-                for name, env in (("rows", {"RVLL_WALK_ROWS": "1"}), ("cu", {"RVLL_WALK_ROWS": "2"}), ("queue", {}), ("one", {"RVLL_WALK_PARTS": "1"})):
+                for name, env in (("rows", {"RVLL_WALK_ROWS": "1"}), ("cu", {"RVLL_WALK_ROWS": "2"}), ("half", {"RVLL_WALK_ROWS": "3"}), ("queue", {}), ("one", {"RVLL_WALK_PARTS": "1"})):
                     for key, val in env.items():
                         monkeypatch.setenv(key, val)
                     runs[name] = m.slice_walk(cube, theta, logl, lstar, chol, wr, nsteps=17, seed=8) + (m.slice_walk_evaluated(),)
                     for key in env:
                         monkeypatch.delenv(key)
-                for name in ("rows", "cu", "queue"):
+                for name in ("rows", "cu", "half", "queue"):
                     got, ref = runs[name], runs["one"]
                     assert all(np.array_equal(a, b) for a, b in zip(got[:3], ref[:3])) and got[3] == ref[3], (k, umax, name)
                     assert got[4] >= got[3]
