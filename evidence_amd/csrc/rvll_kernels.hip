@@ -83,6 +83,8 @@ void scalar_server_kernel(const LoglikeArgs a, ServerCtl* ctl, unsigned long lon
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const Carve cv = carve(a.PB, a.D, a.Np, a.Ni, a.nlin, a.CH);
     unsigned long long* word = reinterpret_cast<unsigned long long*>(smem + cv.total_doubles);   // [0] request, [1] stop
+    LogdetPre pre;                                    // this thread's share of the epoch table for the per-point normalisation:
+    logdet_preload(a, pre);                           // fetched once, it never changes between requests (rvll_tile.h)
     for (;;) {
         if (threadIdx.x == 0) {
             const unsigned long long t0 = wall_clock64();
@@ -118,14 +120,14 @@ void scalar_server_kernel(const LoglikeArgs a, ServerCtl* ctl, unsigned long lon
             __threadfence_system();                   // every thread's theta stores are out before the answer
             __syncthreads();
             if (op == kServerPriorLogLike) {
-                loglike_tile<PREC, kFusedNone>(a, smem, 0, 1, trow);
+                loglike_tile<PREC, kFusedNone, false, kThreads, false, true, true>(a, smem, 0, 1, trow, pre);
                 if (threadIdx.x == 0) {
                     ans.logL = __hip_atomic_load(a.logL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     ans.flags = __hip_atomic_load(a.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
         } else if (op == kServerLogLike) {
-            loglike_tile<PREC, kFusedNone>(a, smem, 0, 1);
+            loglike_tile<PREC, kFusedNone, false, kThreads, false, true, true>(a, smem, 0, 1, nullptr, pre);
             if (threadIdx.x == 0) {                   // thread 0 wrote a.logL[0] / a.flags[0] itself
                 ans.logL = __hip_atomic_load(a.logL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 ans.flags = __hip_atomic_load(a.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -640,12 +640,27 @@ __device__ RVLL_DECODE_INLINE void tile_decode(const LoglikeArgs& __restrict__ a
 //     The order is the point's own (which epochs a lane takes, the row tree), so the bits depend on nothing but the point
 //     and the epoch table: the same in every kernel form, tile size and shard.  ~36 wave instructions a point at 200
 //     epochs against 81 for the logarithms inside the items.
+// lanes per point: a 16-lane row up to 512 epochs, a whole wave beyond (a function of the epoch count alone, so that the
+// order of the sum — and with it the bits — is the same whatever the tile, the kernel form or the shard)
+__device__ __forceinline__ int logdet_group(int Ne) { return Ne > 512 ? kWave : 16; }
+// one lane's (mantissa product, exponent sum) -> its logarithm -> the group's sum in the group's first lane -> acc[pl]
+__device__ __forceinline__ void logdet_finish(const TileLds& L, int pl, int sub, int gs, double m, int e)
+{
+    double v = __builtin_fma((double)e, 6.93147180559945286227e-01, log_pos(m));
+    if (gs == kWave) {
+        v = wave_sum_lane0(v);
+    } else {
+        v += lanes_up_row<8>(v);
+        v += lanes_up_row<4>(v);
+        v += lanes_up_row<2>(v);
+        v += lanes_up_row<1>(v);
+    }
+    if (sub == 0) L.acc[pl] = 0.5 * v;
+}
 template <int NT>
 __device__ __forceinline__ void tile_logdet(const LoglikeArgs& __restrict__ a, const TileLds& L, int npts)
 {
-    // lanes per point: a 16-lane row up to 512 epochs, a whole wave beyond (a function of the epoch count alone, so
-    // that the order of the sum — and with it the bits — is the same whatever the tile, the kernel form or the shard)
-    const int gs = a.Ne > 512 ? kWave : 16;
+    const int gs = logdet_group(a.Ne);
     const int tid = threadIdx.x, sub = tid & (gs - 1);
     for (int pl = tid / gs; pl < npts; pl += NT / gs) {
         const double* jit = L.ins + pl * a.Ni * 2 + 1;
@@ -662,17 +677,46 @@ __device__ __forceinline__ void tile_logdet(const LoglikeArgs& __restrict__ a, c
                 since = 0;
             }
         }
-        double v = __builtin_fma((double)e, 6.93147180559945286227e-01, log_pos(m));
-        if (gs == kWave) {
-            v = wave_sum_lane0(v);
-        } else {
-            v += lanes_up_row<8>(v);
-            v += lanes_up_row<4>(v);
-            v += lanes_up_row<2>(v);
-            v += lanes_up_row<1>(v);
-        }
-        if (sub == 0) L.acc[pl] = 0.5 * v;
+        logdet_finish(L, pl, sub, gs, m, e);
     }
+}
+// The same for a ONE-point tile whose lanes hold their epochs' sigma^2 and instrument numbers in registers already (the
+// persistent scalar-call kernel: the epoch table never changes between requests, and taken from memory these loads are the
+// longest chain of a scalar callback — 9.6 -> 11.3 us, profiles/r03_call_latency.txt).  The same factors in the same
+// order: the same bits.
+constexpr int kLogdetPre = 16;                                     // factors a lane can hold: Ne <= 16 * logdet_group(Ne)
+struct LogdetPre {
+    double s2[kLogdetPre];
+    int inst[kLogdetPre];
+    bool valid;
+};
+__device__ __forceinline__ void logdet_preload(const LoglikeArgs& a, LogdetPre& pre)
+{
+    const int gs = logdet_group(a.Ne), sub = threadIdx.x & (gs - 1);
+    pre.valid = a.Ne <= kLogdetPre * gs;
+#pragma unroll
+    for (int u = 0; u < kLogdetPre; ++u) {
+        const int j = sub + u * gs;
+        const bool in = pre.valid && (int)threadIdx.x < gs && j < a.Ne;
+        pre.s2[u] = in ? a.s2[j] : 1.;
+        pre.inst[u] = in ? a.inst[j] : 0;
+    }
+}
+__device__ __forceinline__ void tile_logdet_pre(const LoglikeArgs& __restrict__ a, const TileLds& L, const LogdetPre& pre)
+{
+    const int gs = logdet_group(a.Ne), tid = threadIdx.x, sub = tid & (gs - 1);
+    if (tid >= gs) return;                                         // (a whole wave or a whole row: the tree's lanes are all here)
+    const double* jit = L.ins + 1;
+    double m = 1.;
+    int e = 0;
+#pragma unroll
+    for (int u = 0; u < kLogdetPre; ++u)
+        if (sub + u * gs < a.Ne) {
+            const double var = pre.s2[u] + jit[pre.inst[u] * 2];
+            m *= __builtin_amdgcn_frexp_mant(var);
+            e += __builtin_amdgcn_frexp_exp(var);
+        }
+    logdet_finish(L, 0, sub, gs, m, e);
 }
 
 // Per-point partial sums of the contributions [lo[k], hi[k]) of up to four points held in contrib[.. - base], each
@@ -740,9 +784,11 @@ __device__ __forceinline__ void tile_write_point(const LoglikeArgs& __restrict__
 // sizes and shard sizes.
 // TRACE: diagnostic build (launch_loglike_trace) — a few s_memrealtime stamps per workgroup go to a.trace, a
 // buffer nothing else reads; no stamp executes in the product kernels.
-template <int PREC, int FUSED, bool TRACE = false, int NT = kThreads, bool DYN = false, bool EXTRAS = true>
+// PRE: the caller holds its lanes' share of the epoch table for the per-point normalisation in registers (LogdetPre; the
+// scalar-call server) — used when the tile has one point and the preload is valid, ignored otherwise
+template <int PREC, int FUSED, bool TRACE = false, int NT = kThreads, bool DYN = false, bool EXTRAS = true, bool PRE = false>
 __device__ __forceinline__ __attribute__((flatten)) void loglike_tile(const LoglikeArgs& __restrict__ a, double* __restrict__ smem, long long p0, int npts,
-                                                                      const double* cube_rows = nullptr)
+                                                                      const double* cube_rows = nullptr, const LogdetPre& pre = LogdetPre{})
 {
     unsigned long long* tr = nullptr;
     if constexpr (TRACE) {
@@ -779,7 +825,9 @@ __device__ __forceinline__ __attribute__((flatten)) void loglike_tile(const Logl
     tile_decode<NT>(a, L, npts);
     __syncthreads();
 #ifndef RVLL_AB_NO_LOGDET
-    tile_logdet<NT>(a, L, npts);          // acc[pl] is next touched behind the barrier that ends the items (3c)
+    bool done_pre = false;
+    if constexpr (PRE) { if (pre.valid && npts == 1) { tile_logdet_pre(a, L, pre); done_pre = true; } }
+    if (!done_pre) tile_logdet<NT>(a, L, npts);       // acc[pl] is next touched behind the barrier that ends the items (3c)
 #endif
     if constexpr (!DYN) __builtin_amdgcn_s_setprio(0);
     if constexpr (TRACE) { if (tid == 0) tr[DYN ? 3 : 1] = __builtin_amdgcn_s_memrealtime(); }

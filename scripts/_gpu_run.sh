@@ -1,3 +1,5 @@
 set -o pipefail
-mkdir -p gpurun_out/r4g
-timeout -k 10 700 python scripts/walk_soak.py --seconds 420 2>&1 | tee gpurun_out/r4g/walk_soak.txt | tail -6
+timeout -k 10 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -2
+python scripts/scalar_latency_ab.py full
+python scripts/scalar_latency_ab.py full
+python bench.py --no-cpu --no-extras | python scripts/show_bench_keys.py /dev/stdin | cut -c1-140
