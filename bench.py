@@ -873,7 +873,7 @@ def launch_self(args):
       * another rank fails      -> rank 0 gets its watchdog's grace to print what it holds (it notices the lost peer by
                                    itself through the rendezvous), then everything is killed;
       * RVLL_LAUNCH_TIMEOUT_S   -> everything is killed.
-    Exit code 0 iff rank 0 printed a line and exited 0.  This is the MPI launcher the reference leaves to its samplers
+    Exit code 0 iff rank 0 printed a line and exited 0 and no rank failed by itself.  This is the MPI launcher the reference leaves to its samplers
     (evidence/polychord/__init__.py:21-29,176-199), reduced to what one node needs."""
     n = args.gpus
     secret = os.urandom(32).hex()
