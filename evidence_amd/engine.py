@@ -81,6 +81,7 @@ class GpuRVModel:
         self._s_in_p, self._s_th_p = _abi.as_dp(self._s_in), _abi.as_dp(self._s_th)
         self._s_out_p, self._s_flag_p = _abi.as_dp(self._s_out), _abi.as_ip(self._s_flag)
         self.priordict = None
+        self._live_n = 0                       # rows of the resident live set (live_init)
         if priordict is not None:
             self.set_priors(priordict)
 
@@ -275,6 +276,8 @@ class GpuRVModel:
         order = np.ascontiguousarray(order, dtype=np.int32)
         start = np.ascontiguousarray(start, dtype=np.int32)
         kdead = int(kdead)
+        if self._live_n < 1:
+            raise RuntimeError("live_init has not been called")
         if order.shape != (self._live_n,) or start.shape != (kdead,):
             raise ValueError("order must list every live row, start one row per dying point")
         wr = None if wrapped is None else np.ascontiguousarray(np.asarray(wrapped, dtype=bool).astype(np.int32))

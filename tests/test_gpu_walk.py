@@ -357,6 +357,8 @@ def test_live_step_api_contract(gpu_required):
     want = np.linalg.cholesky(d0.T @ d0 / (len(keep) - 1) + 1e-14 * np.eye(m.ndim))
     assert np.allclose(chol, want, rtol=1e-10, atol=1e-13) and np.allclose(np.triu(chol, 1), 0.0)
     with GpuRVModel(w.fixedpardict, w.table, w.parnames, priordict=w.priordict()) as m:
-        with pytest.raises(Exception, match="rvll_live_init"):
+        with pytest.raises(RuntimeError, match="live_init"):
+            m.live_step(np.arange(5), 2, np.array([3, 4]), 0.0)
+        with pytest.raises(Exception, match="rvll_live_init"):       # ... and the C-ABI says the same when asked directly
             m._live_n = 5
             m.live_step(np.arange(5), 2, np.array([3, 4]), 0.0)
