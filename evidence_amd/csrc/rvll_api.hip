@@ -152,7 +152,7 @@ void dev_free(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
 constexpr int kMaxLanes = 4;
 // rvll_loglike_batch: host batches from kSplitMinPoints on go up in overlapped chunks of about kSplitChunkPoints
 constexpr long long kSplitMinPoints = 16384, kSplitChunkPoints = 16384, kSplitMaxChunks = 8;   // profiles/r02_split_probe.txt
-constexpr int kWalkWords = 10;                // counters of the walk kernel: calls, tile slots, 4 phase bins + workgroups (diagnostic build)
+constexpr int kWalkWords = 14;                // counters of the walk kernel: calls, tile slots, 4 phase bins + workgroups + longest life + 4 tile phases (diagnostic build), the queue
 constexpr long long kFusedMaxPoints = 4096;   // rvll_prior_loglike_batch: one launch up to here, two beyond
 
 struct rvll_handle {
@@ -1745,6 +1745,9 @@ int walk_core(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t m
     long long total = (long long)evaluated[0];
     h->walk_evaluated = (long long)evaluated[1];
     for (int k = 0; k < 6; ++k) h->walk_phase[k] = evaluated[2 + k];
+    if (getenv("RVLL_WALK_TILE_DUMP") && evaluated[6])       // diagnostic build: the tile's own phases inside the walk (100 MHz ticks)
+        fprintf(stderr, "[walk tile phases, summed over %llu workgroups] stage %llu  decode %llu  items %llu  reduce+write %llu ticks\n",
+                evaluated[6], evaluated[8], evaluated[9], evaluated[10], evaluated[11]);
     if (slim) {
         std::vector<int32_t> ids, start;
         for (int64_t i = 0; i < K; ++i)

@@ -788,8 +788,18 @@ __device__ __forceinline__ void tile_write_point(const LoglikeArgs& __restrict__
 // scalar-call server) — used when the tile has one point and the preload is valid, ignored otherwise
 template <int PREC, int FUSED, bool TRACE = false, int NT = kThreads, bool DYN = false, bool EXTRAS = true, bool PRE = false>
 __device__ __forceinline__ __attribute__((flatten)) void loglike_tile(const LoglikeArgs& __restrict__ a, double* __restrict__ smem, long long p0, int npts,
-                                                                      const double* cube_rows = nullptr, const LogdetPre& pre = LogdetPre{})
+                                                                      const double* cube_rows = nullptr, const LogdetPre& pre = LogdetPre{}
+#ifdef RVLL_WALK_TRACE                 // diagnostic build of the walk only: thread 0 sums the tile's own phases into tph[0..3]
+                                                                      , unsigned long long* tph = nullptr
+#endif
+                                                                      )
 {
+#ifdef RVLL_WALK_TRACE
+    unsigned long long t_last = __builtin_amdgcn_s_memrealtime();
+#define RVLL_TILE_STAMP(k) do { if (tph && threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); tph[k] += now_ - t_last; t_last = now_; } } while (0)
+#else
+#define RVLL_TILE_STAMP(k) do { } while (0)
+#endif
     unsigned long long* tr = nullptr;
     if constexpr (TRACE) {
         tr = a.trace + (size_t)blockIdx.x * kTraceWords;
@@ -813,6 +823,7 @@ __device__ __forceinline__ __attribute__((flatten)) void loglike_tile(const Logl
     if constexpr (!DYN) __builtin_amdgcn_s_setprio(3);
     tile_stage<FUSED, NT>(a, L, p0, npts, TRACE && DYN ? tr + 1 : nullptr, cube_rows);
     __syncthreads();
+    RVLL_TILE_STAMP(0);
     if constexpr (FUSED != kFusedNone && NT == kCuThreads) {
         // theta goes out from LDS in whole rows (the stage's lanes run point-fastest: written there, every store would
         // have been a lone 8 bytes of its cache line); the stores drain under the decode step and the item loop
@@ -828,6 +839,7 @@ __device__ __forceinline__ __attribute__((flatten)) void loglike_tile(const Logl
     bool done_pre = false;
     if constexpr (PRE) { if (pre.valid && npts == 1) { tile_logdet_pre(a, L, pre); done_pre = true; } }
     if (!done_pre) tile_logdet<NT>(a, L, npts);       // acc[pl] is next touched behind the barrier that ends the items (3c)
+    RVLL_TILE_STAMP(1);
 #endif
     if constexpr (!DYN) __builtin_amdgcn_s_setprio(0);
     if constexpr (TRACE) { if (tid == 0) tr[DYN ? 3 : 1] = __builtin_amdgcn_s_memrealtime(); }
@@ -882,6 +894,7 @@ __device__ __forceinline__ __attribute__((flatten)) void loglike_tile(const Logl
             if constexpr (TRACE) { if (lane == 0) tr[2 + wave] = __builtin_amdgcn_s_memrealtime(); }
         }
         __syncthreads();
+        RVLL_TILE_STAMP(2);
         if constexpr (TRACE && DYN) { if (tid == 0) tr[5] = __builtin_amdgcn_s_memrealtime(); }
         // 3b. rare: a solve hit itmax.  The reference aborts that planet's array there
         // and leaves nu = 0 from that epoch on; redo the affected points' items now that
@@ -922,6 +935,8 @@ __device__ __forceinline__ __attribute__((flatten)) void loglike_tile(const Logl
     }
 
     for (int pl = tid; pl < npts; pl += NT) tile_write_point(a, L, p0, pl);
+    RVLL_TILE_STAMP(3);
+#undef RVLL_TILE_STAMP
     if constexpr (TRACE) {
         __syncthreads();
         if (threadIdx.x == 0) tr[6] = __builtin_amdgcn_s_memrealtime();

@@ -183,7 +183,7 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
     // phase clock of a diagnostic build (make walktrace; scripts/walk_phase_probe.py): thread 0 sums the time between
     // barriers into four bins — directions and chord limits / candidates / prior transform + log-L tile / accept + copy
 #ifdef RVLL_WALK_TRACE
-    unsigned long long ph[5] = {0, 0, 0, 0, 0}, last = __builtin_amdgcn_s_memrealtime();
+    unsigned long long ph[5] = {0, 0, 0, 0, 0}, tph[4] = {0, 0, 0, 0}, last = __builtin_amdgcn_s_memrealtime();
 #define WALK_STAMP(k) do { if (tid == 0) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); ph[k] += now - last; last = now; } } while (0)
 #else
 #define WALK_STAMP(k) do { } while (0)
@@ -288,7 +288,11 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
         __syncthreads();
         WALK_STAMP(1);
         // prior transform + log-L of the candidates: rows read from LDS, results left in LDS (and in the scratch rows)
+#ifdef RVLL_WALK_TRACE
+        loglike_tile<PREC, FAT ? kFusedFull : kFusedSlim>(a, smem, w0, nslots, cand, LogdetPre{}, tph);
+#else
         loglike_tile<PREC, FAT ? kFusedFull : kFusedSlim>(a, smem, w0, nslots, cand);
+#endif
         // the walk's own phases are short and serial (a lane per walker, one thread for the bookkeeping): at the
         // default priority they get every fourth issue slot next to three workgroups in their item loops and a
         // barrier-to-barrier phase of ~50 instructions takes 1-2 us (phase clock: 33 % of a workgroup's life for a
@@ -365,6 +369,7 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
         for (int k = 0; k < 4; ++k) atomicAdd(w.nslots + 1 + k, ph[k]);
         atomicAdd(w.nslots + 5, 1ull);
         atomicMax(w.nslots + 6, ph[0] + ph[1] + ph[2] + ph[3]);         // the longest workgroup life of the launch(es)
+        for (int k = 0; k < 4; ++k) atomicAdd(w.nslots + 7 + k, tph[k]);  // the tile's own phases: stage, decode, items, reduce + write
     }
 #endif
 #undef WALK_STAMP
@@ -571,7 +576,7 @@ void slice_walk_rows_kernel(const LoglikeArgs a, const WalkArgs w)
 #endif
     __syncthreads();
 #ifdef RVLL_WALK_TRACE
-    unsigned long long ph[5] = {0, 0, 0, 0, 0}, last = __builtin_amdgcn_s_memrealtime();
+    unsigned long long ph[5] = {0, 0, 0, 0, 0}, tph[4] = {0, 0, 0, 0}, last = __builtin_amdgcn_s_memrealtime();
 #define WALK_STAMP(k) do { if (tid == 0) { const unsigned long long now = __builtin_amdgcn_s_memrealtime(); ph[k] += now - last; last = now; } } while (0)
 #else
 #define WALK_STAMP(k) do { } while (0)
@@ -656,7 +661,11 @@ void slice_walk_rows_kernel(const LoglikeArgs a, const WalkArgs w)
         }
         __syncthreads();
         WALK_STAMP(1);
+#ifdef RVLL_WALK_TRACE
+        loglike_tile<PREC, FAT ? kFusedFull : kFusedSlim, false, NT, DYN>(a, smem, w0, nslots, cand, LogdetPre{}, tph);
+#else
         loglike_tile<PREC, FAT ? kFusedFull : kFusedSlim, false, NT, DYN>(a, smem, w0, nslots, cand);
+#endif
         __builtin_amdgcn_s_setprio(3);
         __syncthreads();
         WALK_STAMP(2);
@@ -716,6 +725,7 @@ void slice_walk_rows_kernel(const LoglikeArgs a, const WalkArgs w)
         for (int k = 0; k < 4; ++k) atomicAdd(w.nslots + 1 + k, ph[k]);
         atomicAdd(w.nslots + 5, 1ull);
         atomicMax(w.nslots + 6, ph[0] + ph[1] + ph[2] + ph[3]);
+        for (int k = 0; k < 4; ++k) atomicAdd(w.nslots + 7 + k, tph[k]);
     }
 #endif
 #undef WALK_STAMP
