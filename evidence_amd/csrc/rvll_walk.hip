@@ -120,64 +120,76 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
         step_of[i] = w.step_start ? w.step_start[g] : 0;
     }
     __syncthreads();
-    // ---- the bookkeeping thread's helpers ----
-    // tile slots of the next iteration: every active walker one, the free ones dealt out evenly, at most spec_max per
-    // walker and never past the move's last round.  (Dealt by each row's own rejection rate instead — the j-th slot of a
-    // walker is used with probability p^(j-1) — 0.5 % more of the evaluated slots were used and the kernel was 3 %
-    // slower: the dealer runs on one thread while the other waves wait.)
-    auto deal_slots = [&](const int* act, int n) {
-        const int base = n ? nw / n : 0, rem = n ? nw % n : 0;
-        int f = 0;
-        for (int ai = 0; ai < n; ++ai) {
-            const int pl = act[ai];
-            int S = min(w.spec_max, base + (ai < rem ? 1 : 0));
-            S = max(1, min(S, w.max_rounds - (state[pl] == 0 ? 0 : round_of[pl])));
-            first_of[pl] = f; nsp_of[pl] = S; f += S;
-        }
-        int ns = 0;
-        for (int ai = 0; ai < n; ++ai) if (state[act[ai]] == 0) starts[ns++] = act[ai];
-        nact_s[0] = n; nact_s[1] = f; nact_s[3] = ns;
-    };
-    // the next row nobody walks yet (rows with nothing left to do are ticked off on the way), or -1
+    // ---- bookkeeping by the LAST WAVE, one lane per walker slot (round 3; as one thread walking the slots it was a chain of
+    //      dependent LDS reads — a tenth of a workgroup's life) ----
+    // A lane accounts for its walker's candidates, moves it on after an accept, and — when the walker is done (all moves
+    // made, or deferred) — marks its row to go home at the top of the next iteration and draws the next row nobody walks yet
+    // from the global ticket counter (rows with nothing left to do are ticked off on the way); a slot that finds none stays
+    // empty (gid = -1).  Then the next iteration's list, its tile slots (every listed walker one, the free ones dealt out
+    // evenly, at most spec_max per walker and never past the move's last round; dealt by each row's own rejection rate
+    // instead, 0.5 % more of the evaluated slots were used and the kernel was 3 % slower) and the walkers that start a move,
+    // all by ballots.  Which slot draws which row is not deterministic any more — nor need it be: the random-number
+    // counters name the row.
     const long long qbase = (long long)gridDim.x * PB;
-    bool queue_empty = false;
-    auto next_row = [&]() -> int {
-        while (!queue_empty) {
-            const long long k = qbase + (long long)atomicAdd(w.queue, 1ull);
-            if (k >= w.K) { queue_empty = true; break; }
-            const int q = row_at(k);
-            const int ss = w.step_start ? w.step_start[q] : 0;
-            if (ss < w.nsteps) return q;
-            if (w.steps_done) w.steps_done[q] = ss;
-            if (w.cost) w.cost[q] = 0;
+    const int lane = tid & (kWave - 1);
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
+    bool queue_empty = false;                               // (per lane; a lane stops asking once it has seen the end)
+    long long calls = 0;                                    // per lane of the bookkeeping wave
+    unsigned long long slots = 0;
+    auto bookkeep = [&](int* act_out, bool first) {
+        const int pl = lane;
+        const bool slot = pl < nw;
+        const bool active = slot && gid[pl] >= 0;
+        int st = active ? state[pl] : 1, stp = active ? step_of[pl] : 0;
+        if (active && !first) { const int u = used_of[pl]; calls += u; cost_of[pl] += u; }
+        if (active && st == 2) { st = 0; stp += 1; }
+        const bool done = active && !(stp < w.nsteps && st != 3);
+        int g = active ? gid[pl] : -1, rf = 0;
+        if (done) {
+            gold[pl] = g;
+            used_of[pl] = cost_of[pl];                      // (carried to the top of the next iteration, where the row goes home)
+            cost_of[pl] = 0;
+            g = -1;
+            while (!queue_empty) {
+                const long long k = qbase + (long long)atomicAdd(w.queue, 1ull);
+                if (k >= w.K) { queue_empty = true; break; }
+                const int q = w.order ? w.order[k] : (int)k;
+                const int ss = w.step_start ? w.step_start[q] : 0;
+                if (ss < w.nsteps) { g = q; break; }
+                if (w.steps_done) w.steps_done[q] = ss;
+                if (w.cost) w.cost[q] = 0;
+            }
+            rf = g >= 0 ? 1 : 2;
+            if (g >= 0) { st = 0; round_of[pl] = 0; }
         }
-        return -1;
-    };
-    // slot pl's walker is done (all moves made, or deferred): its row goes home at the top of the next iteration, where
-    // the slot also loads the row it takes over; returns whether the slot stays in the list
-    auto retire = [&](int pl) -> bool {
-        gold[pl] = gid[pl];
-        used_of[pl] = cost_of[pl];                          // (carried to the top of the next iteration, where the row goes home)
-        cost_of[pl] = 0;
-        const int q = next_row();
-        refill[pl] = q >= 0 ? 1 : 2;
-        if (q < 0) return false;
-        gid[pl] = q; state[pl] = 0; round_of[pl] = 0;
-        return true;
+        if (slot) { refill[pl] = rf; gid[pl] = g; }
+        if (active) { state[pl] = st == 3 ? 0 : st; step_of[pl] = stp; }
+        const bool listed = slot && g >= 0;
+        const unsigned long long m_act = __ballot(listed);
+        const int n = __popcll(m_act), ai = __popcll(m_act & lanes_below);
+        int S = 0;
+        if (listed) {
+            act_out[ai] = pl;
+            S = min(w.spec_max, n ? nw / n + (ai < nw % n ? 1 : 0) : 0);
+            S = max(1, min(S, w.max_rounds - (st == 0 ? 0 : round_of[pl])));
+        }
+        if (slot) nsp_of[pl] = S;
+        int f = 0;
+        for (int k = 0; k < pl && k < nw; ++k) f += nsp_of[k];
+        if (listed) first_of[pl] = f;
+        if (lane == 63 - __builtin_clzll(m_act | 1ull) && listed) nact_s[1] = f + S;       // the last listed slot: the total
+        const bool begins = listed && st == 0;
+        const unsigned long long m_begin = __ballot(begins), m_done = __ballot(done);
+        if (begins) starts[__popcll(m_begin & lanes_below)] = pl;
+        if (lane == 0) {
+            nact_s[0] = n;
+            if (n == 0) nact_s[1] = 0;
+            nact_s[2] = __popcll(m_done);
+            nact_s[3] = __popcll(m_begin);
+        }
     };
     int* const act0 = act;
-    long long calls = 0;                                    // the bookkeeping thread only
-    unsigned long long slots = 0;
-    if (tid == kThreads - 1) {                              // walkers that still have moves to make
-        int n = 0, nref = 0;
-        for (int i = 0; i < nw; ++i) {
-            if (step_of[i] < w.nsteps) { act[n++] = i; continue; }
-            ++nref;
-            if (retire(i)) act[n++] = i;
-        }
-        deal_slots(act, n);
-        nact_s[2] = nref;
-    }
+    if (tid >= kThreads - kWave) bookkeep(act, true);       // walkers that still have moves to make; rows with none go home at once
     __syncthreads();
 
     // phase clock of a diagnostic build (make walktrace; scripts/walk_phase_probe.py): thread 0 sums the time between
@@ -216,9 +228,7 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
         act = act0 + (iter & 1) * PB;
         int* const act_next = act0 + ((iter + 1) & 1) * PB;
         // walkers starting a move: standard normals (Box-Muller on two counter-based uniforms), parked in lo_s ...
-        // (only the walkers that START a move — a third of them per iteration at cfg3 — and those packed into as few waves
-        // as they need: looping over every listed walker and skipping the others kept three partly filled waves busy with
-        // Box-Muller, a tenth of the walk's vector instructions; profiles/r03_walk_forms.txt)
+        // (only the walkers that START a move — a third of them per iteration at cfg3 — draw directions; profiles/r03_walk_forms.txt)
         const int nstart = nact_s[3];
         for (int i = tid; i < nstart * D; i += kThreads) {
             const int pl = starts[i / D], k = i % D;
@@ -336,21 +346,9 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
             wu[pl * D + k] = fmin(fmax(c, 0.), one_below);
             w.theta[(long long)acc_g[pl] * D + k] = L.theta_s[sl * D + k];
         }
-        if (tid == kThreads - 1) {
-            slots += (unsigned long long)nslots;
-            int n = 0, nr = 0;
-            for (int i = 0; i < nw; ++i) refill[i] = 0;                 // last iteration's marks were served at the top
-            for (int ai = 0; ai < nact; ++ai) {
-                const int pl = act[ai];
-                calls += used_of[pl];
-                cost_of[pl] += used_of[pl];
-                if (state[pl] == 2) { state[pl] = 0; step_of[pl] += 1; }
-                if (step_of[pl] < w.nsteps && state[pl] != 3) { act_next[n++] = pl; continue; }
-                ++nr;
-                if (retire(pl)) act_next[n++] = pl;
-            }
-            deal_slots(act_next, n);
-            nact_s[2] = nr;
+        if (tid >= kThreads - kWave) {
+            if (lane == 0) slots += (unsigned long long)nslots;
+            bookkeep(act_next, false);
         }
         __syncthreads();
         WALK_STAMP(3);
@@ -362,8 +360,8 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
         w.u[g * D + k] = wu[pl * D + k];
         if (k == 0) { w.logl[g] = wl[pl]; if (w.steps_done) w.steps_done[g] = step_of[pl]; if (w.cost) w.cost[g] = cost_of[pl]; }
     }
-    if (tid == kThreads - 1 && calls) atomicAdd(w.ncalls, (unsigned long long)calls);   // (two's complement: a negative share adds up right)
-    if (tid == kThreads - 1 && slots && w.nslots) atomicAdd(w.nslots, slots);
+    if (tid >= kThreads - kWave && calls) atomicAdd(w.ncalls, (unsigned long long)calls);   // (two's complement: a negative share adds up right)
+    if (tid >= kThreads - kWave && slots && w.nslots) atomicAdd(w.nslots, slots);
 #ifdef RVLL_WALK_TRACE
     if (tid == 0 && w.nslots) {
         for (int k = 0; k < 4; ++k) atomicAdd(w.nslots + 1 + k, ph[k]);
