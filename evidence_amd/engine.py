@@ -293,20 +293,35 @@ class GpuRVModel:
             int(walker_base), C.byref(ncalls), _abi.as_dp(logl_new), _abi.as_dp(used) if used is not None else None))
         return (logl_new, int(ncalls.value), used) if return_chol else (logl_new, int(ncalls.value))
 
-    def live_get(self):
-        """(cube, theta, logl) of the resident live set."""
+    def live_get(self, cube=True, theta=True, logl=True, theta_out=None):
+        """(cube, theta, logl) of the resident live set (None for the ones switched off); theta_out: a C-contiguous
+        [n, ndim] float64 array (or view) to receive theta in place."""
         n = self._live_n
-        u, th, ll = np.empty((n, self.ndim)), np.empty((n, self.ndim)), np.empty(n)
-        _abi.check(self._lib.rvll_live_get(self._h, _abi.as_dp(u), _abi.as_dp(th), _abi.as_dp(ll)))
+        u = np.empty((n, self.ndim)) if cube else None
+        th = (theta_out if theta_out is not None else np.empty((n, self.ndim))) if theta else None
+        ll = np.empty(n) if logl else None
+        if th is not None and (th.shape != (n, self.ndim) or th.dtype != np.float64 or not th.flags.c_contiguous):
+            raise ValueError("theta_out must be a C-contiguous float64 array of shape (n, ndim)")
+        _abi.check(self._lib.rvll_live_get(self._h, _abi.as_dp(u) if cube else None, _abi.as_dp(th) if theta else None,
+                                           _abi.as_dp(ll) if logl else None))
         return u, th, ll
 
-    def live_dead(self):
-        """(theta, logl) of every point that died so far, in the order they died."""
+    def live_dead_count(self):
         n = C.c_int64(0)
         _abi.check(self._lib.rvll_live_dead(self._h, C.byref(n), None, None))
-        th, ll = np.empty((n.value, self.ndim)), np.empty(n.value)
-        if n.value:
-            _abi.check(self._lib.rvll_live_dead(self._h, C.byref(n), _abi.as_dp(th), _abi.as_dp(ll)))
+        return int(n.value)
+
+    def live_dead(self, theta_out=None):
+        """(theta, logl) of every point that died so far, in the order they died; theta_out: a C-contiguous
+        [n_dead, ndim] float64 array (or view) to receive theta in place."""
+        n = self.live_dead_count()
+        th = theta_out if theta_out is not None else np.empty((n, self.ndim))
+        if th.shape != (n, self.ndim) or th.dtype != np.float64 or not th.flags.c_contiguous:
+            raise ValueError("theta_out must be a C-contiguous float64 array of shape (n_dead, ndim)")
+        ll = np.empty(n)
+        if n:
+            cnt = C.c_int64(n)
+            _abi.check(self._lib.rvll_live_dead(self._h, C.byref(cnt), _abi.as_dp(th), _abi.as_dp(ll)))
         return th, ll
 
     def scalar_server(self, enable=True):

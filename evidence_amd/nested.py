@@ -311,12 +311,19 @@ def run_nested_slice(prior: Callable, loglike: Callable, ndim: int, nlive: Optio
         u[dead], theta[dead], logl[dead] = wu, wt, wl
         if np.max(logl) + logx < logz + np.log(np.expm1(dlogz)):
             break
-    if live is not None:
-        dead_theta = [live.live_dead()[0]]
-        theta = live.live_get()[1]
     logw_live = logx - np.log(nlive) + logl
     logz_final = np.logaddexp(logz, _logaddexp_many(logw_live))
-    all_theta = np.vstack([a.reshape(-1, ndim) for a in dead_theta] + [theta])
+    if live is not None and hasattr(live, "live_dead_count"):
+        # the samples come down once, straight into the array that is returned: dead points first, then the live set
+        ndead = live.live_dead_count()
+        all_theta = np.empty((ndead + nlive, ndim))
+        live.live_dead(theta_out=all_theta[:ndead])
+        live.live_get(cube=False, logl=False, theta_out=all_theta[ndead:])
+    else:
+        if live is not None:
+            dead_theta = [live.live_dead()[0]]
+            theta = live.live_get()[1]
+        all_theta = np.vstack([a.reshape(-1, ndim) for a in dead_theta] + [theta])
     all_logl = np.concatenate(dead_logl + [logl])
     all_logw = np.concatenate(dead_logw + [logw_live]) - logz_final
     return NestedResult(float(logz_final), float(np.sqrt(max(h, 0.0) / nlive)), it, ncall, float(h),
