@@ -6,14 +6,19 @@
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 #include <unordered_map>
 
@@ -153,7 +158,11 @@ constexpr int kMaxLanes = 4;
 // rvll_loglike_batch: host batches from kSplitMinPoints on go up in overlapped chunks of about kSplitChunkPoints
 constexpr long long kSplitMinPoints = 16384, kSplitChunkPoints = 16384, kSplitMaxChunks = 8;   // profiles/r02_split_probe.txt
 constexpr int kWalkWords = 14;                // counters of the walk kernel: calls, tile slots, 4 phase bins + workgroups + longest life + 4 tile phases (diagnostic build), the queue
+constexpr long long kStreamMinPoints = 65536;  // host batches from here on are streamed in chunks with the host's copies on worker threads (stream_host_batch)
 constexpr long long kFusedMaxPoints = 4096;   // rvll_prior_loglike_batch: one launch up to here, two beyond
+
+namespace { class CopyPool; }
+constexpr int kStageSlots = 4;              // pinned staging blocks each way of a streamed host batch (stream_host_batch)
 
 struct rvll_handle {
     int device = 0;
@@ -213,6 +222,15 @@ struct rvll_handle {
     void* pin_out = nullptr;
     void* pin_in_dev = nullptr;      // device-visible aliases of the two pinned buffers (zero-copy path)
     void* pin_out_dev = nullptr;
+
+    // large host batches (stream_host_batch): worker threads for the host's copies, pinned staging blocks, one event per block
+    CopyPool* pool = nullptr;
+    void* stage_in[kStageSlots] = {};
+    void* stage_out[kStageSlots] = {};
+    size_t stage_in_bytes = 0, stage_out_bytes = 0;
+    hipEvent_t stage_ev[kStageSlots] = {};      // a chunk's results are in its pinned block
+    hipEvent_t stage_up[kStageSlots] = {}, stage_done[kStageSlots] = {};   // ... its rows are on the device / its kernels have run
+    hipStream_t stream_up = nullptr, stream_down = nullptr;                // the two copy directions, beside lane 0's kernels
 
     // scalar-call server (rvll_scalar_server): persistent one-workgroup kernel + host-coherent control block
     rvll::ServerCtl* srv = nullptr;             // pinned, mapped, coherent
@@ -292,6 +310,7 @@ int server_stop(rvll_handle* h)
 }
 
 int resolve_fused(rvll_handle* h);
+void stream_free(rvll_handle* h);
 
 int use_device(rvll_handle* h)
 {
@@ -699,6 +718,7 @@ int rvll_destroy(rvll_handle* h)
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     if (h->pin_defer) (void)hipHostFree(h->pin_defer);
+    stream_free(h);
     dev_free(h->d_walk_steps); dev_free(h->d_walk_wid); dev_free(h->d_walk_start);
     for (auto& e : h->marks) if (e) (void)hipEventDestroy(e);
     if (h->srv_stream) (void)hipStreamDestroy(h->srv_stream);
@@ -1265,6 +1285,254 @@ int scalar_call(rvll_handle* h, unsigned op, const double* theta, double* logL, 
     return RVLL_OK;
 }
 
+
+// ---- large host batches: a pipeline of chunks, the host's copies on worker threads (round 3) --------------------------
+// A 262144-point cube -> theta -> log-L call moves 80 MB between the caller's pageable arrays and the device.  Through copy
+// commands on pageable memory that is ONE host thread at ~12 GB/s (the runtime's staging copy on the way up, ours — into a
+// freshly mapped result array, page faults included — on the way down): 6.5 ms around 1.2 ms of kernels (the
+// "cliff").  Here the batch goes in chunks of 16384 rows through pinned staging blocks: worker threads copy chunk c + 2 in
+// and chunk c - 1 out while the DMA engines and the kernels work on chunk c (uploads, kernels and downloads each on a stream of
+// their own, chained by events: the link carries both directions at once).
+// The same kernels on the same rows: the same bits (tests/test_gpu_boundary.py runs every size class).
+class CopyPool {
+public:
+    struct Ticket { std::atomic<int> left{0}; };
+    explicit CopyPool(int n) { for (int i = 0; i < n; ++i) workers_.emplace_back([this] { run(); }); }
+    ~CopyPool()
+    {
+        { std::lock_guard<std::mutex> g(m_); stop_ = true; }
+        cv_.notify_all();
+        for (auto& t : workers_) t.join();
+    }
+    int size() const { return (int)workers_.size(); }
+    // while a call is running the workers poll for work; between calls they sleep
+    void busy(bool on)
+    {
+        { std::lock_guard<std::mutex> g(m_); busy_ = on; }
+        if (on) cv_.notify_all();
+    }
+    // dst <- src in page-aligned pieces, one per worker at most and none below 128 KB; the ticket counts the pieces still to do
+    void copy(void* dst, const void* src, size_t bytes, Ticket* t)
+    {
+        if (!bytes) return;
+        const size_t pieces = std::max<size_t>(1, std::min<size_t>(workers_.size(), bytes / (128u << 10)));
+        const size_t step = ((bytes + pieces - 1) / pieces + 4095) & ~(size_t)4095;
+        const int n = (int)((bytes + step - 1) / step);
+        t->left.fetch_add(n, std::memory_order_relaxed);
+        {
+            std::lock_guard<std::mutex> g(m_);
+            for (size_t off = 0; off < bytes; off += step)
+                q_.push_back({static_cast<char*>(dst) + off, static_cast<const char*>(src) + off, std::min(step, bytes - off), t});
+            queued_.store((int)q_.size(), std::memory_order_release);
+        }
+        if (!busy_) cv_.notify_all();
+    }
+    static void wait(Ticket* t)
+    {
+        for (unsigned spins = 0; t->left.load(std::memory_order_acquire) > 0; ++spins)
+            if (spins < 4096) __builtin_ia32_pause(); else std::this_thread::yield();
+    }
+private:
+    struct Task { char* dst; const char* src; size_t bytes; Ticket* t; };
+    void run()
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {
+            if (!q_.empty()) {
+                const Task k = q_.front();
+                q_.pop_front();
+                queued_.store((int)q_.size(), std::memory_order_release);
+                lk.unlock();
+                memcpy(k.dst, k.src, k.bytes);
+                k.t->left.fetch_sub(1, std::memory_order_release);
+                lk.lock();
+            } else if (stop_) {
+                return;
+            } else if (busy_) {
+                lk.unlock();                    // (poll without the lock: eight idle workers taking it every microsecond slowed the caller)
+                for (int i = 0; i < 4096 && queued_.load(std::memory_order_acquire) == 0; ++i) __builtin_ia32_pause();
+                lk.lock();
+            } else {
+                cv_.wait(lk);
+            }
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<Task> q_;
+    std::vector<std::thread> workers_;
+    std::atomic<int> queued_{0};
+    bool stop_ = false, busy_ = false;
+};
+
+constexpr long long kStreamChunkRows = 16384;
+long long stream_min_points()
+{
+    if (const char* e = getenv("RVLL_STREAM_MIN")) return std::max(1ll, atoll(e));      // measurement switch
+    return kStreamMinPoints;
+}
+
+void stream_free(rvll_handle* h)
+{
+    delete h->pool;
+    h->pool = nullptr;
+    for (int s = 0; s < kStageSlots; ++s) {
+        if (h->stage_in[s]) (void)hipHostFree(h->stage_in[s]);
+        if (h->stage_out[s]) (void)hipHostFree(h->stage_out[s]);
+        for (hipEvent_t* e : {&h->stage_ev[s], &h->stage_up[s], &h->stage_done[s]}) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
+        h->stage_in[s] = h->stage_out[s] = nullptr;
+    }
+    if (h->stream_up) (void)hipStreamDestroy(h->stream_up);
+    if (h->stream_down) (void)hipStreamDestroy(h->stream_down);
+    h->stream_up = h->stream_down = nullptr;
+    h->stage_in_bytes = h->stage_out_bytes = 0;
+}
+
+// workers, events and staging blocks for chunks of `rows` rows (grown on demand, kept with the handle)
+int stream_reserve(rvll_handle* h, long long rows)
+{
+    const size_t D = (size_t)h->L.ndim;
+    const size_t in_bytes = sizeof(double) * D * (size_t)rows;
+    const size_t out_bytes = (sizeof(double) * (D + 1) + sizeof(int32_t)) * (size_t)rows;
+    if (!h->pool) {
+        int n = (int)std::min(8u, std::max(2u, std::thread::hardware_concurrency() / 2));
+        if (const char* e = getenv("RVLL_COPY_THREADS")) n = std::max(1, std::min(32, atoi(e)));
+        h->pool = new (std::nothrow) CopyPool(n);
+        if (!h->pool) return fail(RVLL_E_NOMEM, "no memory for the copy workers");
+    }
+    for (int s = 0; s < kStageSlots; ++s)
+        for (hipEvent_t* e : {&h->stage_ev[s], &h->stage_up[s], &h->stage_done[s]})
+            if (!*e) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    if (!h->stream_up) HIP_TRY(hipStreamCreateWithFlags(&h->stream_up, hipStreamNonBlocking));
+    if (!h->stream_down) HIP_TRY(hipStreamCreateWithFlags(&h->stream_down, hipStreamNonBlocking));
+    if (in_bytes > h->stage_in_bytes || out_bytes > h->stage_out_bytes) {
+        for (int s = 0; s < kStageSlots; ++s) {
+            if (h->stage_in[s]) (void)hipHostFree(h->stage_in[s]);
+            if (h->stage_out[s]) (void)hipHostFree(h->stage_out[s]);
+            h->stage_in[s] = h->stage_out[s] = nullptr;
+        }
+        h->stage_in_bytes = h->stage_out_bytes = 0;
+        for (int s = 0; s < kStageSlots; ++s) {
+            HIP_TRY(hipHostMalloc(&h->stage_in[s], in_bytes, hipHostMallocDefault));
+            HIP_TRY(hipHostMalloc(&h->stage_out[s], out_bytes, hipHostMallocDefault));
+        }
+        h->stage_in_bytes = in_bytes;
+        h->stage_out_bytes = out_bytes;
+    }
+    return RVLL_OK;
+}
+
+// rows of `in` (unit-cube rows if in_is_cube, else theta rows) -> [theta_out], logL, [flags], all host arrays of B rows
+int stream_host_batch(rvll_handle* h, const double* in, bool in_is_cube, int64_t B, double* theta_out, double* logL, int32_t* flags)
+{
+    long long rows = kStreamChunkRows;
+    if (const char* e = getenv("RVLL_STREAM_CHUNK")) rows = std::max(256, atoi(e));      // measurement switch
+    int rc = rvll_dev_reserve(h, B);
+    if (rc) return rc;
+    rc = sync_other_lanes(h);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->compute));
+    rc = stream_reserve(h, rows);
+    if (rc) return rc;
+    const long long D = h->L.ndim;
+    const int n = (int)((B + rows - 1) / rows);
+    CopyPool& pool = *h->pool;
+    CopyPool::Ticket tin[kStageSlots], tout[kStageSlots];
+    auto lo_of = [&](int c) { return (long long)c * rows; };
+    auto hi_of = [&](int c) { return std::min<long long>(B, (long long)(c + 1) * rows); };
+    auto copy_in = [&](int c) {
+        if (c < n) pool.copy(h->stage_in[c % kStageSlots], in + lo_of(c) * D, sizeof(double) * (size_t)((hi_of(c) - lo_of(c)) * D), &tin[c % kStageSlots]);
+    };
+    auto copy_out = [&](int c) {
+        const long long lo = lo_of(c), m = hi_of(c) - lo;
+        const char* so = static_cast<const char*>(h->stage_out[c % kStageSlots]);
+        CopyPool::Ticket* t = &tout[c % kStageSlots];
+        if (theta_out) pool.copy(theta_out + lo * D, so, sizeof(double) * (size_t)(m * D), t);
+        pool.copy(logL + lo, so + sizeof(double) * (size_t)(rows * D), sizeof(double) * (size_t)m, t);
+        if (flags) pool.copy(flags + lo, so + sizeof(double) * (size_t)(rows * (D + 1)), sizeof(int32_t) * (size_t)m, t);
+    };
+    hipStream_t s_up = h->stream_up, s_down = h->stream_down;
+    int lag = 2;    // the calling thread runs this many chunks ahead of the results it waits for (1: the next chunk's commands were
+                    // issued only when the last-but-one's results had landed, and the kernels waited for that: 2.3 -> 1.8 ms at 262144 rows)
+    if (const char* e = getenv("RVLL_STREAM_LANES")) {                                   // measurement switch
+        if (e[0] == 'l') { s_up = h->lanes[1]; s_down = h->lanes[2]; }
+        if (e[0] == 'o') { s_up = h->lanes[1]; s_down = h->lanes[1]; }
+        if (e[0] == 'x') { s_up = h->lanes[2]; s_down = h->lanes[1]; }
+    }
+    if (const char* e = getenv("RVLL_STREAM_LAG")) lag = std::max(1, std::min(2, atoi(e)));
+    // whatever happens, leave with no copy in flight into or out of the caller's arrays and the workers asleep
+    auto settle = [&](int code) {
+        for (int s = 0; s < kStageSlots; ++s) { CopyPool::wait(&tin[s]); CopyPool::wait(&tout[s]); }
+        (void)hipStreamSynchronize(s_up);
+        (void)hipStreamSynchronize(h->compute);
+        (void)hipStreamSynchronize(s_down);
+        pool.busy(false);
+        return code;
+    };
+#define STREAM_TRY(expr) do { const hipError_t err_ = (expr); if (err_ != hipSuccess) { settle(0); HIP_TRY(err_); } } while (0)
+    const bool timing = getenv("RVLL_STREAM_TIMING") != nullptr;                          // measurement switch: where the calling thread waits
+    double waited[4] = {0., 0., 0., 0.};
+    auto now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_start = timing ? now() : 0.;
+    pool.busy(true);
+    copy_in(0);
+    copy_in(1);
+    double* dev_in = in_is_cube ? h->d_cube : h->d_theta;
+    for (int c = 0; c < n; ++c) {
+        const int s = c % kStageSlots;
+        const long long lo = lo_of(c), m = hi_of(c) - lo;
+        double t0 = timing ? now() : 0.;
+        CopyPool::wait(&tin[s]);                            // the chunk's rows are in their pinned block ...
+        if (timing) { const double t1 = now(); waited[0] += t1 - t0; t0 = t1; }
+        CopyPool::wait(&tout[s]);                           // ... and the results of the chunk that used the block before are out of theirs
+        if (timing) { const double t1 = now(); waited[1] += t1 - t0; t0 = t1; }
+        // up | kernels | down on three streams, so that chunk c + 1 comes up and chunk c - 1 goes down (the link is full duplex)
+        // under the kernels of chunk c
+        STREAM_TRY(hipMemcpyAsync(dev_in + lo * D, h->stage_in[s], sizeof(double) * (size_t)(m * D), hipMemcpyHostToDevice, s_up));
+        STREAM_TRY(hipEventRecord(h->stage_up[s], s_up));
+        STREAM_TRY(hipStreamWaitEvent(h->compute, h->stage_up[s], 0));
+        if (in_is_cube) {
+            rvll::PriorArgs pa{h->d_cube + lo * D, h->d_theta + lo * D, m, h->L.ndim, h->d_priors, h->d_heavy, h->n_heavy};
+            STREAM_TRY(rvll::launch_prior(pa, h->compute));
+        }
+        rvll::LoglikeArgs a;
+        int cu = 0;
+        rc = build_args(h, h->d_theta + lo * D, h->d_logL2[0] + lo, h->d_flags2[0] + lo, m, &a, &cu);
+        if (rc) return settle(rc);
+        STREAM_TRY(launch_form(a, cu, h->compute));
+        STREAM_TRY(hipEventRecord(h->stage_done[s], h->compute));
+        STREAM_TRY(hipStreamWaitEvent(s_down, h->stage_done[s], 0));
+        char* so = static_cast<char*>(h->stage_out[s]);
+        hipStream_t st = s_down;
+        if (theta_out) STREAM_TRY(hipMemcpyAsync(so, h->d_theta + lo * D, sizeof(double) * (size_t)(m * D), hipMemcpyDeviceToHost, st));
+        STREAM_TRY(hipMemcpyAsync(so + sizeof(double) * (size_t)(rows * D), h->d_logL2[0] + lo, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, st));
+        if (flags) STREAM_TRY(hipMemcpyAsync(so + sizeof(double) * (size_t)(rows * (D + 1)), h->d_flags2[0] + lo, sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost, st));
+        STREAM_TRY(hipEventRecord(h->stage_ev[s], st));
+        if (timing) { const double t1 = now(); waited[2] += t1 - t0; t0 = t1; }
+        if (c >= lag) {
+            STREAM_TRY(hipEventSynchronize(h->stage_ev[(c - lag) % kStageSlots]));
+            if (timing) { const double t1 = now(); waited[3] += t1 - t0; t0 = t1; }
+            copy_out(c - lag);
+        }
+        copy_in(c + 2);     // (its block was last read by the upload of chunk c - 2, whose event has been waited for)
+    }
+    for (int c = std::max(0, n - lag); c < n; ++c) {
+        STREAM_TRY(hipEventSynchronize(h->stage_ev[c % kStageSlots]));
+        copy_out(c);
+    }
+#undef STREAM_TRY
+    h->theta_async = false;
+    h->logl_last = 0;
+    if (timing) {
+        const double t1 = now();
+        settle(0);
+        fprintf(stderr, "stream %lld rows, %d chunks, %d workers: %.0f us to the last event, %.0f us in all; waited for rows in %.0f, results out %.0f, "
+                "issue %.0f, events %.0f us\n", (long long)B, n, pool.size(), t1 - t_start, now() - t_start, waited[0], waited[1], waited[2], waited[3]);
+        return RVLL_OK;
+    }
+    return settle(RVLL_OK);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1312,6 +1580,9 @@ int rvll_loglike_batch(rvll_handle* h, const double* theta, int64_t B, double* l
         if (flags) memcpy(flags, static_cast<char*>(h->pin_out) + sizeof(double) * (size_t)B, sizeof(int32_t) * (size_t)B);
         return RVLL_OK;
     }
+    // (theta -> log-L has no large download: the runtime's own staged upload from pageable memory is as fast as ours and the
+    //  chunked route below wins at every size, fresh arrays or kept ones — profiles/r03_stream_probe.txt; streamed only by switch)
+    if (getenv("RVLL_STREAM_LOGLIKE") && B >= stream_min_points()) return stream_host_batch(h, theta, false, B, nullptr, logL, flags);
     int nsplit = B >= kSplitMinPoints ? (int)std::min<long long>(kSplitMaxChunks, std::max<long long>(2, B / kSplitChunkPoints)) : 1;
     if (const char* e = getenv("RVLL_SPLIT")) nsplit = std::max(1, std::min(64, atoi(e)));   // measurement switch
     if (nsplit > 1 && B >= 2 * nsplit) {
@@ -1462,6 +1733,7 @@ int rvll_prior_loglike_batch(rvll_handle* h, const double* cube, int64_t B,
         if (theta_out) memcpy(theta_out, host_out + theta_off, nin);
         return RVLL_OK;
     }
+    if (B >= stream_min_points()) return stream_host_batch(h, cube, true, B, theta_out, logL, flags);
     // measured (profiles/r01_split_probe.txt): two halves help from 16384 points (+15 %) to 65536 (+35 %); more chunks
     // lose to the per-copy fixed costs, and at 262144 points the large pageable downloads on two streams collapse
     int nsplit = (B >= kSplitMinPoints && B <= 131072) ? 2 : 1;

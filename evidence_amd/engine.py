@@ -7,6 +7,8 @@ plus the batched forms the GPU exists for.  Every evaluation goes through the C-
 (include/rvll.h) into the HIP kernels; there is no host implementation.
 """
 import ctypes as C
+import threading
+import weakref
 from typing import Dict, Optional, Sequence
 
 import numpy as np
@@ -15,6 +17,53 @@ from . import _abi
 from .data import EpochTable
 from .layout import compile_layout
 from .priors import PriorSpec
+
+
+# ---- large result arrays ---------------------------------------------------------------------------------
+# A float64 array above glibc's 32 MB mmap threshold is a fresh mapping every time it is made and an munmap when it dies:
+# 2.7 ms of page faults for the 40 MB of theta rows a 262144-point call returns — more than the call itself (1.8 ms;
+# profiles/r03_stream_probe.txt).  Results of that size are therefore handed out from a small store of blocks that come back
+# when the LAST array looking at them (the result or any view of it) is collected: the array's base is a lease object, numpy
+# keeps it alive exactly as long as the memory is referenced, and its finalizer returns the block.
+_RESULT_MIN_BYTES = 32 << 20
+_RESULT_KEEP = 4                      # blocks kept for reuse (of any size); more are simply freed
+_result_blocks = []                   # uint8 arrays
+_result_lock = threading.RLock()      # (re-entrant: a lease's finalizer may run inside _result_array, at any allocation)
+
+
+class _Lease:
+    __slots__ = ("__array_interface__", "__weakref__")
+
+    def __init__(self, block, shape):
+        iface = dict(block.__array_interface__)
+        iface.update(shape=tuple(shape), typestr="<f8", descr=[("", "<f8")], strides=None)
+        self.__array_interface__ = iface
+
+
+def _give_back(block):
+    with _result_lock:
+        if len(_result_blocks) < _RESULT_KEEP:
+            _result_blocks.append(block)
+
+
+def _result_array(shape):
+    """An uninitialised C-contiguous float64 array of `shape` (np.empty below 32 MB)."""
+    nbytes = 8 * int(np.prod(shape))
+    if nbytes < _RESULT_MIN_BYTES:
+        return np.empty(shape, dtype=np.float64)
+    block = None
+    with _result_lock:
+        for i, b in enumerate(_result_blocks):
+            if b.nbytes == nbytes:
+                block = _result_blocks.pop(i)
+                break
+        if block is None and len(_result_blocks) >= _RESULT_KEEP:
+            _result_blocks.pop(0)     # make room: the oldest block of another size goes
+    if block is None:
+        block = np.empty(nbytes, dtype=np.uint8)
+    lease = _Lease(block, shape)
+    weakref.finalize(lease, _give_back, block)
+    return np.asarray(lease)
 
 
 class GpuRVModel:
@@ -128,6 +177,13 @@ class GpuRVModel:
             raise ValueError(f"expected an array of shape (n, {self.ndim}), got {x.shape}")
         return x
 
+    @staticmethod
+    def _out_array(a, shape, name):
+        if not (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags.c_contiguous and a.flags.writeable
+                and a.shape == tuple(shape)):
+            raise ValueError(f"{name}: expected a writeable C-contiguous float64 array of shape {tuple(shape)}")
+        return a
+
     def log_likelihood_batch(self, X, return_flags=False):
         """log-L of every row of X[n, ndim] -> float64[n] (one fused kernel launch)."""
         X = self._theta2d(X)
@@ -176,7 +232,7 @@ class GpuRVModel:
     # ---- prior transform --------------------------------------------------------------------
     def prior_transform_batch(self, cubes):
         cubes = self._theta2d(cubes)
-        out = np.empty_like(cubes)
+        out = _result_array(cubes.shape)
         _abi.check(self._lib.rvll_prior_batch(self._h, _abi.as_dp(cubes), cubes.shape[0], _abi.as_dp(out)))
         return out
 
@@ -202,12 +258,16 @@ class GpuRVModel:
             _abi.check(rc)
         return self._s_th[0, :self.ndim].copy().reshape(cube.shape), float(self._s_out[0])
 
-    def prior_loglike_batch(self, cubes, return_flags=False):
-        """Fused prior(cube) -> theta -> log-L: one upload, two launches, one download."""
+    def prior_loglike_batch(self, cubes, return_flags=False, theta_out=None, logl_out=None):
+        """Fused prior(cube) -> theta -> log-L: one upload, two launches, one download.
+
+        theta_out / logl_out: arrays to fill (C-contiguous float64, (n, ndim) and (n,)) — a caller that evaluates hundreds of
+        thousands of rows per call keeps them between calls: above glibc's 32 MB mmap threshold a fresh result array is a
+        fresh mapping, and its page faults cost more than the whole call (profiles/r03_stream_probe.txt)."""
         cubes = self._theta2d(cubes)
         n = cubes.shape[0]
-        theta = np.empty_like(cubes)
-        out = np.empty(n, dtype=np.float64)
+        theta = _result_array((n, self.ndim)) if theta_out is None else self._out_array(theta_out, (n, self.ndim), "theta_out")
+        out = np.empty(n, dtype=np.float64) if logl_out is None else self._out_array(logl_out, (n,), "logl_out")
         flags = np.zeros(n, dtype=np.int32)
         _abi.check(self._lib.rvll_prior_loglike_batch(self._h, _abi.as_dp(cubes), n, _abi.as_dp(theta),
                                                       _abi.as_dp(out), _abi.as_ip(flags)))
@@ -353,7 +413,7 @@ class GpuRVModel:
 
     def dev_download(self, n, theta=False, logl=True, flags=False):
         n = int(n)
-        th = np.empty((n, self.ndim), dtype=np.float64) if theta else None
+        th = _result_array((n, self.ndim)) if theta else None
         ll = np.empty(n, dtype=np.float64) if logl else None
         fl = np.empty(n, dtype=np.int32) if flags else None
         _abi.check(self._lib.rvll_dev_download(

@@ -220,7 +220,11 @@ int rvll_loglike_batch(rvll_handle* h, const double* theta, int64_t B,
                        double* logL, int32_t* flags);
 /* cube: [B, D] in [0,1].  theta: [B, D].                                     */
 int rvll_prior_batch(rvll_handle* h, const double* cube, int64_t B, double* theta);
-/* fused: one H2D, prior + log-L launches back to back, one D2H               */
+/* fused: one H2D, prior + log-L launches back to back, one D2H.
+ * From 65536 rows on the batch is streamed: chunks of 16384 rows through pinned staging blocks, uploads, kernels and
+ * downloads on three streams, and the copies between the caller's (pageable) arrays and the blocks on worker
+ * threads of the library — 2 to 8, RVLL_COPY_THREADS overrides; started by the first such call of a handle, asleep
+ * between calls, joined by rvll_destroy.  The caller's arrays are only touched between entry and return.           */
 int rvll_prior_loglike_batch(rvll_handle* h, const double* cube, int64_t B,
                              double* theta_out, double* logL, int32_t* flags);
 

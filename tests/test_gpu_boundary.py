@@ -300,6 +300,42 @@ def test_large_host_batches_go_up_in_overlapped_chunks(gpu_required, n, monkeypa
     assert np.array_equal(got, whole) and np.array_equal(flags, flags1) and np.array_equal(seven, whole)
 
 
+@pytest.mark.parametrize("chunk,workers,lag", [(4096, 3, 2), (16384, 8, 2), (30000, 1, 1)])
+def test_streamed_host_batches_are_the_device_resident_bits(gpu_required, monkeypatch, chunk, workers, lag):
+    """Host batches of 65536 rows and more go through pinned staging blocks in chunks, the host's copies on worker threads
+    (csrc/rvll_api.hip, stream_host_batch): the same kernels on the same rows.  Forced here for every size (ragged last
+    chunk, fewer rows than a chunk, fewer chunks than the pipeline is deep), into fresh, recycled and caller-owned arrays."""
+    n = 230_001                                                           # 35 MB of rows: a recycled result block (engine.py)
+    w = make_workload(3)
+    cube = w.sample_cube(n, seed=5)
+    cube[::1013] *= 1e-9
+    monkeypatch.setenv("RVLL_COPY_THREADS", str(workers))
+    with GpuRVModel(w.fixedpardict, w.table, w.parnames, priordict=w.priordict()) as m:
+        m.dev_upload_cube(cube); m.dev_prior(n); m.dev_loglike(n)
+        theta, logl, flags = (a.copy() for a in m.dev_download(n, theta=True, flags=True))
+        monkeypatch.setenv("RVLL_STREAM_MIN", "1")
+        monkeypatch.setenv("RVLL_STREAM_CHUNK", str(chunk))
+        monkeypatch.setenv("RVLL_STREAM_LAG", str(lag))
+        for k in (n, 3, chunk - 1, chunk, chunk + 1, 2 * chunk + 7, 70_000):
+            for rep in range(2):                                          # (the second call of the full size reuses the first one's block)
+                th, ll, fl = m.prior_loglike_batch(cube[:k], return_flags=True)
+                assert np.array_equal(th, theta[:k]) and np.array_equal(ll, logl[:k]) and np.array_equal(fl, flags[:k]), k
+                del th
+            ll, fl = m.log_likelihood_batch(theta[:k], return_flags=True)
+            assert np.array_equal(ll, logl[:k]) and np.array_equal(fl, flags[:k]), k
+        mine_t, mine_l = np.full((n, m.ndim), np.nan), np.full(n, np.nan)
+        th, ll = m.prior_loglike_batch(cube, theta_out=mine_t, logl_out=mine_l)
+        assert th is mine_t and ll is mine_l and np.array_equal(mine_t, theta) and np.array_equal(mine_l, logl)
+        with pytest.raises(ValueError, match="theta_out"):
+            m.prior_loglike_batch(cube, theta_out=mine_t[:-1])
+        with pytest.raises(ValueError, match="logl_out"):
+            m.prior_loglike_batch(cube, logl_out=mine_l.astype(np.float32))
+        # and the routes it replaced, on the same handle afterwards
+        monkeypatch.setenv("RVLL_STREAM_MIN", str(1 << 40))
+        th, ll = m.prior_loglike_batch(cube[:70_000])
+        assert np.array_equal(th, theta[:70_000]) and np.array_equal(ll, logl[:70_000])
+
+
 def test_scalar_server_answers_polychord_style_calls(gpu_required):
     """The persistent scalar-call kernel (rvll_scalar_server): same bits as the launch-per-call path, flags
     included; survives interleaved batch / prior calls (each stops it), its own idle exit, a second model with
