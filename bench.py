@@ -309,6 +309,23 @@ def run_extras(out, model, w, theta, B, with_cpu):
             model.log_likelihood_batch(theta)
         out["host_roundtrip_evals_per_s"] = 10 * B / (time.perf_counter() - t1)
 
+    def large_host_batch():               # cube -> theta -> log-L through host arrays at 262144 rows (40 MB each way): the
+        model.set_priors(w.priordict())   # streamed route (rvll_api.hip, stream_host_batch); a fresh cube array every call
+        n, reps, tot = 262144, 10, 0.0
+        src = w.sample_cube(n, seed=17)
+        t_warm, warm = time.perf_counter(), 0
+        while time.perf_counter() - t_warm < 0.3:      # (the CPU baseline before the extras left the GPU idle for seconds: clocks)
+            model.prior_loglike_batch(src.copy())
+            warm += 1
+        for r in range(reps):
+            cube = src.copy()
+            t1 = time.perf_counter()
+            model.prior_loglike_batch(cube)
+            tot += time.perf_counter() - t1
+        out["host_cube_to_logl_262144_rows"] = {"evals_per_s": reps * n / tot, "ms_per_call": tot / reps * 1e3, "calls_timed": reps,
+                                                 "warm_up_calls": warm, "input": "a fresh 40 MB array every call"}
+        model.dev_upload_theta(theta)     # (the resident batch of the extras that follow)
+
     def two_lanes():                      # two launches in flight on alternating pipeline lanes (how the N > 1 step
         for _ in range(100):              # overlaps its all-gather): independent batches hide each other's ramp and tail
             model.dev_loglike(B); model.dev_flip_lane()
@@ -422,7 +439,7 @@ def run_extras(out, model, w, theta, B, with_cpu):
     def fip():
         out["fip_periodogram"] = fip_extra(with_cpu)
 
-    for name, fn in (("host_roundtrip", host_roundtrip), ("two_lanes", two_lanes), ("prior_plus_loglike", prior_plus_loglike),
+    for name, fn in (("host_roundtrip", host_roundtrip), ("large_host_batch", large_host_batch), ("two_lanes", two_lanes), ("prior_plus_loglike", prior_plus_loglike),
                      ("scalar_calls", scalar_calls), ("nested_sampling", nested_sampling), ("fip", fip)):
         guarded(name, fn)
 

@@ -176,6 +176,11 @@ def load():
         raise RvllLibraryError(
             f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             f"or `make -C evidence_amd/csrc`. evidence_amd has no CPU fallback.")
+    # The HIP runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and reads the variable when it
+    # starts.  A handle has seven streams; when a copy stream of the streamed host batches shares the kernels' queue, every
+    # chunk's kernels wait for a download (csrc/rvll_api.hip, stream_reserve: 3.3 against 2.0 ms at 262144 rows).  Ask for 8
+    # unless the user has chosen; results do not depend on it.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     try:
         lib = C.CDLL(str(path))
     except OSError as exc:

@@ -158,7 +158,7 @@ constexpr int kMaxLanes = 4;
 // rvll_loglike_batch: host batches from kSplitMinPoints on go up in overlapped chunks of about kSplitChunkPoints
 constexpr long long kSplitMinPoints = 16384, kSplitChunkPoints = 16384, kSplitMaxChunks = 8;   // profiles/r02_split_probe.txt
 constexpr int kWalkWords = 14;                // counters of the walk kernel: calls, tile slots, 4 phase bins + workgroups + longest life + 4 tile phases (diagnostic build), the queue
-constexpr long long kStreamMinPoints = 65536;  // host batches from here on are streamed in chunks with the host's copies on worker threads (stream_host_batch)
+constexpr size_t kStreamMinBytes = 24u << 20;   // cube -> theta -> log-L host batches whose rows take this much are streamed (stream_host_batch)
 constexpr long long kFusedMaxPoints = 4096;   // rvll_prior_loglike_batch: one launch up to here, two beyond
 
 namespace { class CopyPool; }
@@ -230,7 +230,7 @@ struct rvll_handle {
     size_t stage_in_bytes = 0, stage_out_bytes = 0;
     hipEvent_t stage_ev[kStageSlots] = {};      // a chunk's results are in its pinned block
     hipEvent_t stage_up[kStageSlots] = {}, stage_done[kStageSlots] = {};   // ... its rows are on the device / its kernels have run
-    hipStream_t stream_up = nullptr, stream_down = nullptr;                // the two copy directions, beside lane 0's kernels
+    hipStream_t stream_up = nullptr, stream_down = nullptr;                // the two copy directions, beside lane 0's kernels (stream_reserve)
 
     // scalar-call server (rvll_scalar_server): persistent one-workgroup kernel + host-coherent control block
     rvll::ServerCtl* srv = nullptr;             // pinned, mapped, coherent
@@ -1366,10 +1366,14 @@ private:
 };
 
 constexpr long long kStreamChunkRows = 16384;
-long long stream_min_points()
+// Streamed from 24 MB of rows on (165565 points at 19 parameters).  Below, the two-chunk route copies straight from and to the
+// caller's arrays and is level or ahead (131072 rows: 1.04 - 1.08 ms against 1.0 - 1.2 ms); above, the caller's arrays are
+// fresh mappings every call (glibc's 32 MB mmap threshold), the runtime's cache of pinned ranges misses, and that route
+// collapses (262144 rows: 3.5 - 4.1 ms against 1.9 - 2.2 ms; profiles/r03_stream_probe.txt).  RVLL_STREAM_MIN (points): measurement switch.
+long long stream_min_points(const rvll_handle* h)
 {
-    if (const char* e = getenv("RVLL_STREAM_MIN")) return std::max(1ll, atoll(e));      // measurement switch
-    return kStreamMinPoints;
+    if (const char* e = getenv("RVLL_STREAM_MIN")) return std::max(1ll, atoll(e));
+    return (long long)((kStreamMinBytes + sizeof(double) * (size_t)h->L.ndim - 1) / (sizeof(double) * (size_t)h->L.ndim));
 }
 
 void stream_free(rvll_handle* h)
@@ -1403,8 +1407,18 @@ int stream_reserve(rvll_handle* h, long long rows)
     for (int s = 0; s < kStageSlots; ++s)
         for (hipEvent_t* e : {&h->stage_ev[s], &h->stage_up[s], &h->stage_done[s]})
             if (!*e) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
-    if (!h->stream_up) HIP_TRY(hipStreamCreateWithFlags(&h->stream_up, hipStreamNonBlocking));
-    if (!h->stream_down) HIP_TRY(hipStreamCreateWithFlags(&h->stream_down, hipStreamNonBlocking));
+    if (!h->stream_up) {
+        // The runtime maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4; this handle alone has seven
+        // streams), and a copy's completion marker holds up whatever else shares its queue.  When one of the two copy streams
+        // lands on the kernels' queue, every chunk's kernels wait for the previous chunk's download: 3.3 against 2.0 ms at
+        // 262144 rows — and which stream lands where depends on what the process has done before (inside bench.py streams made
+        // here collided and the handle's spare lanes did not; in the standalone probe it was the other way round; stream
+        // priorities changed nothing).  The Python host therefore asks for 8 queues before the runtime starts
+        // (evidence_amd/_abi.py); a C caller sets GPU_MAX_HW_QUEUES=8 in its environment.  Results are the
+        // same either way.
+        HIP_TRY(hipStreamCreateWithFlags(&h->stream_up, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&h->stream_down, hipStreamNonBlocking));
+    }
     if (in_bytes > h->stage_in_bytes || out_bytes > h->stage_out_bytes) {
         for (int s = 0; s < kStageSlots; ++s) {
             if (h->stage_in[s]) (void)hipHostFree(h->stage_in[s]);
@@ -1454,12 +1468,7 @@ int stream_host_batch(rvll_handle* h, const double* in, bool in_is_cube, int64_t
     hipStream_t s_up = h->stream_up, s_down = h->stream_down;
     int lag = 2;    // the calling thread runs this many chunks ahead of the results it waits for (1: the next chunk's commands were
                     // issued only when the last-but-one's results had landed, and the kernels waited for that: 2.3 -> 1.8 ms at 262144 rows)
-    if (const char* e = getenv("RVLL_STREAM_LANES")) {                                   // measurement switch
-        if (e[0] == 'l') { s_up = h->lanes[1]; s_down = h->lanes[2]; }
-        if (e[0] == 'o') { s_up = h->lanes[1]; s_down = h->lanes[1]; }
-        if (e[0] == 'x') { s_up = h->lanes[2]; s_down = h->lanes[1]; }
-    }
-    if (const char* e = getenv("RVLL_STREAM_LAG")) lag = std::max(1, std::min(2, atoi(e)));
+    if (const char* e = getenv("RVLL_STREAM_LAG")) lag = std::max(1, std::min(2, atoi(e)));   // measurement switch
     // whatever happens, leave with no copy in flight into or out of the caller's arrays and the workers asleep
     auto settle = [&](int code) {
         for (int s = 0; s < kStageSlots; ++s) { CopyPool::wait(&tin[s]); CopyPool::wait(&tout[s]); }
@@ -1582,7 +1591,7 @@ int rvll_loglike_batch(rvll_handle* h, const double* theta, int64_t B, double* l
     }
     // (theta -> log-L has no large download: the runtime's own staged upload from pageable memory is as fast as ours and the
     //  chunked route below wins at every size, fresh arrays or kept ones — profiles/r03_stream_probe.txt; streamed only by switch)
-    if (getenv("RVLL_STREAM_LOGLIKE") && B >= stream_min_points()) return stream_host_batch(h, theta, false, B, nullptr, logL, flags);
+    if (getenv("RVLL_STREAM_LOGLIKE") && B >= stream_min_points(h)) return stream_host_batch(h, theta, false, B, nullptr, logL, flags);
     int nsplit = B >= kSplitMinPoints ? (int)std::min<long long>(kSplitMaxChunks, std::max<long long>(2, B / kSplitChunkPoints)) : 1;
     if (const char* e = getenv("RVLL_SPLIT")) nsplit = std::max(1, std::min(64, atoi(e)));   // measurement switch
     if (nsplit > 1 && B >= 2 * nsplit) {
@@ -1733,7 +1742,7 @@ int rvll_prior_loglike_batch(rvll_handle* h, const double* cube, int64_t B,
         if (theta_out) memcpy(theta_out, host_out + theta_off, nin);
         return RVLL_OK;
     }
-    if (B >= stream_min_points()) return stream_host_batch(h, cube, true, B, theta_out, logL, flags);
+    if (B >= stream_min_points(h)) return stream_host_batch(h, cube, true, B, theta_out, logL, flags);
     // measured (profiles/r01_split_probe.txt): two halves help from 16384 points (+15 %) to 65536 (+35 %); more chunks
     // lose to the per-copy fixed costs, and at 262144 points the large pageable downloads on two streams collapse
     int nsplit = (B >= kSplitMinPoints && B <= 131072) ? 2 : 1;

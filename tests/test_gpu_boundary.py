@@ -302,7 +302,7 @@ def test_large_host_batches_go_up_in_overlapped_chunks(gpu_required, n, monkeypa
 
 @pytest.mark.parametrize("chunk,workers,lag", [(4096, 3, 2), (16384, 8, 2), (30000, 1, 1)])
 def test_streamed_host_batches_are_the_device_resident_bits(gpu_required, monkeypatch, chunk, workers, lag):
-    """Host batches of 65536 rows and more go through pinned staging blocks in chunks, the host's copies on worker threads
+    """Host batches of 24 MB of rows and more go through pinned staging blocks in chunks, the host's copies on worker threads
     (csrc/rvll_api.hip, stream_host_batch): the same kernels on the same rows.  Forced here for every size (ragged last
     chunk, fewer rows than a chunk, fewer chunks than the pipeline is deep), into fresh, recycled and caller-owned arrays."""
     n = 230_001                                                           # 35 MB of rows: a recycled result block (engine.py)
@@ -411,7 +411,7 @@ def test_every_transport_threshold_one_row_either_side(gpu_required):
     independent, so a call on any slice of one table returns the bits of those rows computed once through the
     device-resident path — at every threshold, one row below and one above (scripts/host_call_soak.py soaks the same
     with random sizes; profiles/r02_host_call_soak.txt)."""
-    nbig = 140_000
+    nbig = 166_000
     w = make_workload(3)
     rng = np.random.default_rng(9)
     cube = w.sample_cube(nbig, seed=43)
@@ -421,7 +421,7 @@ def test_every_transport_threshold_one_row_either_side(gpu_required):
         m.dev_upload_cube(cube); m.dev_prior(nbig); m.dev_loglike(nbig)
         theta, logl, flags = (a.copy() for a in m.dev_download(nbig, theta=True, flags=True))
         sizes = {1, 2, 63, 64, 65, 4095, 4096, 4097, 16383, 16384, 16385, 65535, 65536, 65537, 131071, 131072, 131073, nbig}
-        for T in (64 << 10, 384 << 10, 1 << 20, 8 << 20):
+        for T in (64 << 10, 384 << 10, 1 << 20, 8 << 20, 24 << 20):       # (the last: where streamed chunks take over)
             for r in (8 * D, 16 * D, 12, 8 * D + 12, 16 * D + 12):
                 n = T // r
                 sizes.update(k for k in (n - 1, n, n + 1) if 1 <= k <= nbig)
