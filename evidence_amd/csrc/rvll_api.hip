@@ -1399,7 +1399,8 @@ int stream_reserve(rvll_handle* h, long long rows)
     const size_t in_bytes = sizeof(double) * D * (size_t)rows;
     const size_t out_bytes = (sizeof(double) * (D + 1) + sizeof(int32_t)) * (size_t)rows;
     if (!h->pool) {
-        int n = (int)std::min(8u, std::max(2u, std::thread::hardware_concurrency() / 2));
+        // (2, 4 and 8 workers measure the same within the run-to-run spread — the GPU side of the pipeline is the longer one)
+        int n = (int)std::min(4u, std::max(2u, std::thread::hardware_concurrency() / 2));
         if (const char* e = getenv("RVLL_COPY_THREADS")) n = std::max(1, std::min(32, atoi(e)));
         h->pool = new (std::nothrow) CopyPool(n);
         if (!h->pool) return fail(RVLL_E_NOMEM, "no memory for the copy workers");

@@ -223,7 +223,7 @@ int rvll_prior_batch(rvll_handle* h, const double* cube, int64_t B, double* thet
 /* fused: one H2D, prior + log-L launches back to back, one D2H.
  * From 24 MB of rows on (165565 points at 19 parameters) the batch is streamed: chunks of 16384 rows through pinned staging blocks, uploads, kernels and
  * downloads on three streams, and the copies between the caller's (pageable) arrays and the blocks on worker
- * threads of the library — 2 to 8, RVLL_COPY_THREADS overrides; started by the first such call of a handle, asleep
+ * threads of the library — 2 to 4, RVLL_COPY_THREADS overrides; started by the first such call of a handle, asleep
  * between calls, joined by rvll_destroy.  The caller's arrays are only touched between entry and return.           */
 int rvll_prior_loglike_batch(rvll_handle* h, const double* cube, int64_t B,
                              double* theta_out, double* logL, int32_t* flags);
