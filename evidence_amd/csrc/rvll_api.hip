@@ -311,6 +311,10 @@ int server_stop(rvll_handle* h)
 
 int resolve_fused(rvll_handle* h);
 void stream_free(rvll_handle* h);
+int download_rows(rvll_handle* h, void* dst, const void* src_dev, size_t bytes);
+// device -> pageable host copies from here on go through download_rows: arrays the caller makes per call (above glibc's mmap threshold
+// every array is a fresh mapping), and the dead points' one download per run into an array made for it
+constexpr size_t kDownloadStagedMin = 32u << 20, kDeadStagedMin = 8u << 20;
 
 int use_device(rvll_handle* h)
 {
@@ -1018,28 +1022,14 @@ int rvll_dev_download(rvll_handle* h, int64_t B, double* theta, double* logL, in
             // range and cached that — which it cannot for a range it has never seen: 38 MB of theta into a fresh numpy
             // array take 20-28 ms (1.5 GB/s), and numpy arrays above 32 MB are fresh mappings every time (glibc's mmap
             // threshold stops growing there; below it the heap hands the same block out again and the copy is fast:
-            // profiles/r02_d2h_probe.txt).  From 32 MB on the rows therefore go through the two 1 MiB pinned blocks, the
-            // copy of chunk i+1 under the memcpy of chunk i: 6 ms for those 38 MB.  Below, directly (the staged route
-            // costs 3x there).
-            constexpr size_t kDirectMax = (32u << 20) - 1, kChunk = rvll_handle::kPinBytes;
-            if (nt <= kDirectMax) {
+            // profiles/r02_d2h_probe.txt).  Large downloads therefore go through pinned staging blocks, the workers
+            // copying chunk c to its place while chunks c + 1 .. c + 3 land (download_rows; round 2: two 1 MiB blocks on
+            // the calling thread, 6 ms for those 38 MB).
+            if (nt < kDownloadStagedMin) {
                 HIP_TRY(hipMemcpyAsync(theta, h->d_theta, nt, hipMemcpyDeviceToHost, h->compute));
             } else {
-                HIP_TRY(hipStreamSynchronize(h->compute));
-                char* dst = reinterpret_cast<char*>(theta);
-                const char* src = reinterpret_cast<const char*>(h->d_theta);
-                void* stage[2] = {h->pin_in, h->pin_out};
-                const size_t nchunks = (nt + kChunk - 1) / kChunk;
-                HIP_TRY(hipMemcpyAsync(stage[0], src, std::min(kChunk, nt), hipMemcpyDeviceToHost, h->compute));
-                for (size_t c = 0; c < nchunks; ++c) {
-                    const size_t off = c * kChunk, len = std::min(kChunk, nt - off);
-                    HIP_TRY(hipStreamSynchronize(h->compute));                    // chunk c has landed
-                    if (c + 1 < nchunks)
-                        HIP_TRY(hipMemcpyAsync(stage[(c + 1) & 1], src + off + kChunk, std::min(kChunk, nt - off - kChunk),
-                                               hipMemcpyDeviceToHost, h->lanes[1]));
-                    memcpy(dst + off, stage[c & 1], len);
-                    if (c + 1 < nchunks) HIP_TRY(hipStreamSynchronize(h->lanes[1]));
-                }
+                rc = download_rows(h, theta, h->d_theta, nt);
+                if (rc) return rc;
             }
         }
         if (logL)  HIP_TRY(hipMemcpyAsync(logL, h->d_logL2[h->logl_last], nl, hipMemcpyDeviceToHost, h->compute));
@@ -1435,6 +1425,53 @@ int stream_reserve(rvll_handle* h, long long rows)
         h->stage_out_bytes = out_bytes;
     }
     return RVLL_OK;
+}
+
+// A large device array into the caller's pageable memory: chunks through the pinned staging blocks on the download stream, up to
+// three in flight, each copied on to its place by the workers as it lands (a copy command straight into pageable memory runs
+// at 50 GB/s into a range the runtime has pinned and cached, at 1.5 - 7 GB/s into one it has never seen — and a result array
+// usually is one; round 2 staged through two 1 MiB blocks on the calling thread: 6 ms for 38 MB).  Work queued on lane 0's
+// stream before the call is waited for first.
+int download_rows(rvll_handle* h, void* dst, const void* src_dev, size_t bytes)
+{
+    if (!bytes) return RVLL_OK;
+    int rc = stream_reserve(h, kStreamChunkRows);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->compute));
+    const size_t chunk = h->stage_out_bytes & ~(size_t)4095;
+    const int n = (int)((bytes + chunk - 1) / chunk);
+    CopyPool& pool = *h->pool;
+    CopyPool::Ticket tout[kStageSlots];
+    char* to = static_cast<char*>(dst);
+    const char* from = static_cast<const char*>(src_dev);
+    auto settle = [&](int code) {
+        for (int s = 0; s < kStageSlots; ++s) CopyPool::wait(&tout[s]);
+        (void)hipStreamSynchronize(h->stream_down);
+        pool.busy(false);
+        return code;
+    };
+#define DOWN_TRY(expr) do { const hipError_t err_ = (expr); if (err_ != hipSuccess) { settle(0); HIP_TRY(err_); } } while (0)
+    auto fetch = [&](int c) -> hipError_t {
+        const int s = c % kStageSlots;
+        const size_t off = (size_t)c * chunk;
+        hipError_t e = hipMemcpyAsync(h->stage_out[s], from + off, std::min(chunk, bytes - off), hipMemcpyDeviceToHost, h->stream_down);
+        return e != hipSuccess ? e : hipEventRecord(h->stage_ev[s], h->stream_down);
+    };
+    pool.busy(true);
+    for (int c = 0; c < std::min(n, kStageSlots - 1); ++c) DOWN_TRY(fetch(c));
+    for (int c = 0; c < n; ++c) {
+        const int s = c % kStageSlots;
+        const size_t off = (size_t)c * chunk;
+        DOWN_TRY(hipEventSynchronize(h->stage_ev[s]));
+        pool.copy(to + off, h->stage_out[s], std::min(chunk, bytes - off), &tout[s]);
+        const int next = c + kStageSlots - 1;               // its block held chunk c - 1: wait until the workers have emptied it
+        if (next < n) {
+            CopyPool::wait(&tout[next % kStageSlots]);
+            DOWN_TRY(fetch(next));
+        }
+    }
+#undef DOWN_TRY
+    return settle(RVLL_OK);
 }
 
 // rows of `in` (unit-cube rows if in_is_cube, else theta rows) -> [theta_out], logL, [flags], all host arrays of B rows
@@ -2273,8 +2310,11 @@ int rvll_live_get(rvll_handle* h, double* cube, double* theta, double* logl)
     if (h->live_n < 1) return fail(RVLL_E_INVALID, "rvll_live_init has not been called");
     const size_t D = (size_t)h->L.ndim, N = (size_t)h->live_n;
     hipStream_t st = h->compute;
-    if (cube) HIP_TRY(hipMemcpyAsync(cube, h->d_live_u, sizeof(double) * D * N, hipMemcpyDeviceToHost, st));
-    if (theta) HIP_TRY(hipMemcpyAsync(theta, h->d_live_theta, sizeof(double) * D * N, hipMemcpyDeviceToHost, st));
+    const bool staged = sizeof(double) * D * N >= kDownloadStagedMin;
+    if (cube && staged) { rc = download_rows(h, cube, h->d_live_u, sizeof(double) * D * N); if (rc) return rc; }
+    else if (cube) HIP_TRY(hipMemcpyAsync(cube, h->d_live_u, sizeof(double) * D * N, hipMemcpyDeviceToHost, st));
+    if (theta && staged) { rc = download_rows(h, theta, h->d_live_theta, sizeof(double) * D * N); if (rc) return rc; }
+    else if (theta) HIP_TRY(hipMemcpyAsync(theta, h->d_live_theta, sizeof(double) * D * N, hipMemcpyDeviceToHost, st));
     if (logl) HIP_TRY(hipMemcpyAsync(logl, h->d_live_logl, sizeof(double) * N, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return RVLL_OK;
@@ -2289,7 +2329,12 @@ int rvll_live_dead(rvll_handle* h, int64_t* n_dead, double* theta, double* logl)
     *n_dead = have;
     const size_t D = (size_t)h->L.ndim;
     hipStream_t st = h->compute;
-    if (want > 0 && theta) HIP_TRY(hipMemcpyAsync(theta, h->d_dead_theta, sizeof(double) * D * (size_t)want, hipMemcpyDeviceToHost, st));
+    if (want > 0 && theta && sizeof(double) * D * (size_t)want >= kDeadStagedMin) {
+        rc = download_rows(h, theta, h->d_dead_theta, sizeof(double) * D * (size_t)want);
+        if (rc) return rc;
+    } else if (want > 0 && theta) {
+        HIP_TRY(hipMemcpyAsync(theta, h->d_dead_theta, sizeof(double) * D * (size_t)want, hipMemcpyDeviceToHost, st));
+    }
     if (want > 0 && logl) HIP_TRY(hipMemcpyAsync(logl, h->d_dead_logl, sizeof(double) * (size_t)want, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return RVLL_OK;
