@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <exception>
 #include <mutex>
 #include <new>
 #include <string>
@@ -27,6 +28,7 @@
 #include "rvll.h"
 #pragma GCC visibility pop
 #include "rvll_kernels.h"
+#include "rvll_copypool.h"
 
 namespace {
 
@@ -161,7 +163,7 @@ constexpr int kWalkWords = 14;                // counters of the walk kernel: ca
 constexpr size_t kStreamMinBytes = 24u << 20;   // cube -> theta -> log-L host batches whose rows take this much are streamed (stream_host_batch)
 constexpr long long kFusedMaxPoints = 4096;   // rvll_prior_loglike_batch: one launch up to here, two beyond
 
-namespace { class CopyPool; }
+using rvll::CopyPool;
 constexpr int kStageSlots = 4;              // pinned staging blocks each way of a streamed host batch (stream_host_batch)
 
 struct rvll_handle {
@@ -1284,77 +1286,6 @@ int scalar_call(rvll_handle* h, unsigned op, const double* theta, double* logL, 
 // and chunk c - 1 out while the DMA engines and the kernels work on chunk c (uploads, kernels and downloads each on a stream of
 // their own, chained by events: the link carries both directions at once).
 // The same kernels on the same rows: the same bits (tests/test_gpu_boundary.py runs every size class).
-class CopyPool {
-public:
-    struct Ticket { std::atomic<int> left{0}; };
-    explicit CopyPool(int n) { for (int i = 0; i < n; ++i) workers_.emplace_back([this] { run(); }); }
-    ~CopyPool()
-    {
-        { std::lock_guard<std::mutex> g(m_); stop_ = true; }
-        cv_.notify_all();
-        for (auto& t : workers_) t.join();
-    }
-    int size() const { return (int)workers_.size(); }
-    // while a call is running the workers poll for work; between calls they sleep
-    void busy(bool on)
-    {
-        { std::lock_guard<std::mutex> g(m_); busy_ = on; }
-        if (on) cv_.notify_all();
-    }
-    // dst <- src in page-aligned pieces, one per worker at most and none below 128 KB; the ticket counts the pieces still to do
-    void copy(void* dst, const void* src, size_t bytes, Ticket* t)
-    {
-        if (!bytes) return;
-        const size_t pieces = std::max<size_t>(1, std::min<size_t>(workers_.size(), bytes / (128u << 10)));
-        const size_t step = ((bytes + pieces - 1) / pieces + 4095) & ~(size_t)4095;
-        const int n = (int)((bytes + step - 1) / step);
-        t->left.fetch_add(n, std::memory_order_relaxed);
-        {
-            std::lock_guard<std::mutex> g(m_);
-            for (size_t off = 0; off < bytes; off += step)
-                q_.push_back({static_cast<char*>(dst) + off, static_cast<const char*>(src) + off, std::min(step, bytes - off), t});
-            queued_.store((int)q_.size(), std::memory_order_release);
-        }
-        if (!busy_) cv_.notify_all();
-    }
-    static void wait(Ticket* t)
-    {
-        for (unsigned spins = 0; t->left.load(std::memory_order_acquire) > 0; ++spins)
-            if (spins < 4096) __builtin_ia32_pause(); else std::this_thread::yield();
-    }
-private:
-    struct Task { char* dst; const char* src; size_t bytes; Ticket* t; };
-    void run()
-    {
-        std::unique_lock<std::mutex> lk(m_);
-        for (;;) {
-            if (!q_.empty()) {
-                const Task k = q_.front();
-                q_.pop_front();
-                queued_.store((int)q_.size(), std::memory_order_release);
-                lk.unlock();
-                memcpy(k.dst, k.src, k.bytes);
-                k.t->left.fetch_sub(1, std::memory_order_release);
-                lk.lock();
-            } else if (stop_) {
-                return;
-            } else if (busy_) {
-                lk.unlock();                    // (poll without the lock: eight idle workers taking it every microsecond slowed the caller)
-                for (int i = 0; i < 4096 && queued_.load(std::memory_order_acquire) == 0; ++i) __builtin_ia32_pause();
-                lk.lock();
-            } else {
-                cv_.wait(lk);
-            }
-        }
-    }
-    std::mutex m_;
-    std::condition_variable cv_;
-    std::deque<Task> q_;
-    std::vector<std::thread> workers_;
-    std::atomic<int> queued_{0};
-    bool stop_ = false, busy_ = false;
-};
-
 constexpr long long kStreamChunkRows = 16384;
 // Streamed from 24 MB of rows on (165565 points at 19 parameters).  Below, the two-chunk route copies straight from and to the
 // caller's arrays and is level or ahead (131072 rows: 1.04 - 1.08 ms against 1.0 - 1.2 ms); above, the caller's arrays are
@@ -1392,8 +1323,12 @@ int stream_reserve(rvll_handle* h, long long rows)
         // (2, 4 and 8 workers measure the same within the run-to-run spread — the GPU side of the pipeline is the longer one)
         int n = (int)std::min(4u, std::max(2u, std::thread::hardware_concurrency() / 2));
         if (const char* e = getenv("RVLL_COPY_THREADS")) n = std::max(1, std::min(32, atoi(e)));
-        h->pool = new (std::nothrow) CopyPool(n);
-        if (!h->pool) return fail(RVLL_E_NOMEM, "no memory for the copy workers");
+        try {
+            h->pool = new CopyPool(n);
+        } catch (const std::exception& e) {             // (no memory, or the system refuses more threads)
+            h->pool = nullptr;
+            return fail(RVLL_E_NOMEM, "cannot start %d copy workers: %s", n, e.what());
+        }
     }
     for (int s = 0; s < kStageSlots; ++s)
         for (hipEvent_t* e : {&h->stage_ev[s], &h->stage_up[s], &h->stage_done[s]})
