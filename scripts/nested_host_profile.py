@@ -23,3 +23,14 @@ with GpuRVModel(w.fixedpardict, w.table, w.parnames, priordict=w.priordict()) as
     dt = time.perf_counter() - t0
     print(f"{res.ncall} calls in {dt:.3f} s = {res.ncall / dt:.3e}/s")
     pstats.Stats(pr).sort_stats("tottime").print_stats(18)
+    # the same with the live set resident on the device (rvll_live_*): what is left on the host
+    live_kw = {k: v for k, v in kw.items() if k not in ("prior_loglike", "walker")}
+    run_nested_slice(None, None, m.ndim, live=m, **dict(live_kw, max_calls=5_000_000))
+    pr = cProfile.Profile()
+    t0 = time.perf_counter()
+    pr.enable()
+    res = run_nested_slice(None, None, m.ndim, live=m, **live_kw)
+    pr.disable()
+    dt = time.perf_counter() - t0
+    print(f"resident live set: {res.ncall} calls in {dt:.3f} s = {res.ncall / dt:.3e}/s")
+    pstats.Stats(pr).sort_stats("tottime").print_stats(14)
