@@ -22,7 +22,7 @@ NBIG = 300_000
 def edges(D):
     out = {1, 2, 3, 63, 64, 65, 511, 512, 513, 4095, 4096, 4097, 16383, 16384, 16385, 32767, 32768, 32769,
            65535, 65536, 65537, 131071, 131072, 131073, 262144, NBIG}
-    for T in (64 << 10, 384 << 10, 1 << 20, 8 << 20, 32 << 20):
+    for T in (64 << 10, 384 << 10, 1 << 20, 8 << 20, 24 << 20, 32 << 20):
         for r in (8 * D, 16 * D, 12, 16, 8 * D + 12, 16 * D + 12, 8):
             n = T // r
             out.update(k for k in (n - 1, n, n + 1) if 1 <= k <= NBIG)
