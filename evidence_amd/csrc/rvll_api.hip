@@ -23,12 +23,7 @@
 #include <vector>
 #include <unordered_map>
 
-// the C-ABI entry points are the only exported symbols (built with -fvisibility=hidden)
-#pragma GCC visibility push(default)
-#include "rvll.h"
-#pragma GCC visibility pop
-#include "rvll_kernels.h"
-#include "rvll_copypool.h"
+#include "rvll_host.h"      // the handle, HIP_TRY, what the other host units share
 
 namespace {
 
@@ -65,225 +60,9 @@ int report_error(int code, const char* fmt, ...)
 }
 }  // namespace rvll
 
-namespace {
-
-#define HIP_TRY(expr)                                                               \
-    do {                                                                            \
-        hipError_t e_ = (expr);                                                     \
-        if (e_ != hipSuccess)                                                       \
-            return fail(e_ == hipErrorOutOfMemory ? RVLL_E_NOMEM : RVLL_E_HIP,      \
-                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),      \
-                        __FILE__, __LINE__);                                        \
-    } while (0)
-
-// ---- RCCL, resolved at run time so the library loads on boxes without it ----
-struct Id128 { char bytes[RVLL_COMM_ID_BYTES]; };   // ncclUniqueId, passed by value
-static_assert(sizeof(Id128) == 128, "ncclUniqueId is 128 bytes");
-struct Rccl {
-    void* lib = nullptr;
-    int (*GetUniqueId)(void*) = nullptr;
-    int (*CommInitRank)(void**, int, Id128, int) = nullptr;
-    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
-    int (*CommDestroy)(void*) = nullptr;
-    int (*CommSplit)(void*, int, int, void**, void*) = nullptr;     // optional (second pipeline lane)
-    const char* (*GetErrorString)(int) = nullptr;
-};
-constexpr int kNcclFloat64 = 8;   // ncclDouble / ncclFloat64 in rccl.h
-
-Rccl g_rccl;
-
-std::string g_rccl_path;      // where the loaded librccl lives (dladdr)
-int g_rccl_version = 0;       // ncclGetVersion
-
-std::string lib_path_of(const void* symbol)
-{
-    Dl_info info;
-    return (symbol && dladdr(symbol, &info) && info.dli_fname) ? std::string(info.dli_fname) : std::string("?");
-}
-
-// Which librccl: the one next to the HIP runtime this library is linked against — the ROCm it was built and tested
-// with — not whatever a soname lookup finds first (a process that imported torch first would get torch's bundled
-// RCCL and HIP runtime).  Order: RVLL_RCCL_PATH, the directory of the loaded libamdhip64, /opt/rocm/lib, sonames.
-int rccl_load()
-{
-    if (g_rccl.lib) return RVLL_OK;
-    std::vector<std::string> names;
-    if (const char* e = getenv("RVLL_RCCL_PATH")) names.push_back(e);
-    const std::string hip = lib_path_of(reinterpret_cast<const void*>(&hipGetDeviceCount));
-    const size_t slash = hip.rfind('/');
-    if (slash != std::string::npos) {
-        names.push_back(hip.substr(0, slash) + "/librccl.so.1");
-        names.push_back(hip.substr(0, slash) + "/librccl.so");
-    }
-    names.push_back("/opt/rocm/lib/librccl.so.1");
-    names.push_back("librccl.so.1");
-    names.push_back("librccl.so");
-    void* lib = nullptr;
-    std::string tried;
-    for (const std::string& n : names) {
-        lib = dlopen(n.c_str(), RTLD_NOW | RTLD_LOCAL);
-        if (lib) break;
-        tried += n + " ";
-    }
-    if (!lib) return fail(RVLL_E_RCCL, "cannot dlopen librccl (tried %s): %s", tried.c_str(), dlerror());
-    Rccl r;
-    r.lib = lib;
-    r.GetUniqueId    = (int (*)(void*))dlsym(lib, "ncclGetUniqueId");
-    r.CommInitRank   = (int (*)(void**, int, Id128, int))dlsym(lib, "ncclCommInitRank");
-    r.AllGather      = (int (*)(const void*, void*, size_t, int, void*, hipStream_t))dlsym(lib, "ncclAllGather");
-    r.CommDestroy    = (int (*)(void*))dlsym(lib, "ncclCommDestroy");
-    r.CommSplit      = (int (*)(void*, int, int, void**, void*))dlsym(lib, "ncclCommSplit");
-    r.GetErrorString = (const char* (*)(int))dlsym(lib, "ncclGetErrorString");
-    if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy || !r.GetErrorString) {
-        dlclose(lib);
-        return fail(RVLL_E_RCCL, "librccl lacks an expected nccl* symbol");
-    }
-    g_rccl = r;
-    g_rccl_path = lib_path_of(reinterpret_cast<const void*>(r.AllGather));
-    if (auto ver = (int (*)(int*))dlsym(lib, "ncclGetVersion")) (void)ver(&g_rccl_version);
-    return RVLL_OK;
-}
-
-#define RCCL_TRY(expr)                                                              \
-    do {                                                                            \
-        int r_ = (expr);                                                            \
-        if (r_ != 0)                                                                \
-            return fail(RVLL_E_RCCL, "%s failed: %s", #expr, g_rccl.GetErrorString(r_)); \
-    } while (0)
-
-template <typename T>
-void dev_free(T*& p) { if (p) { (void)hipFree(p); p = nullptr; } }
-
-}  // namespace
-
-constexpr int kMaxLanes = 4;
-// rvll_loglike_batch: host batches from kSplitMinPoints on go up in overlapped chunks of about kSplitChunkPoints
-constexpr long long kSplitMinPoints = 16384, kSplitChunkPoints = 16384, kSplitMaxChunks = 8;   // profiles/r02_split_probe.txt
-constexpr int kWalkWords = 14;                // counters of the walk kernel: calls, tile slots, 4 phase bins + workgroups + longest life + 4 tile phases (diagnostic build), the queue
-constexpr size_t kStreamMinBytes = 24u << 20;   // cube -> theta -> log-L host batches whose rows take this much are streamed (stream_host_batch)
-constexpr long long kFusedMaxPoints = 4096;   // rvll_prior_loglike_batch: one launch up to here, two beyond
-
-using rvll::CopyPool;
-constexpr int kStageSlots = 4;              // pinned staging blocks each way of a streamed host batch (stream_host_batch)
-
-struct rvll_handle {
-    int device = 0;
-    hipStream_t compute = nullptr;          // lane 0: every single-GPU call runs here
-    hipStream_t lanes[kMaxLanes] = {};      // lanes[0] == compute; further pipeline lanes of the multi-GPU step (rvll_allgather_logl)
-    int      nlanes_dev = 2;                // lanes rvll_dev_flip_lane cycles through
-
-    // layout (host mirror, then device copies)
-    rvll_layout L{};
-    std::vector<rvll_planet> planets;
-    std::vector<rvll_inst>   insts;
-    std::vector<rvll_slot>   linslots;
-    rvll_planet* d_planets = nullptr;
-    rvll_inst*   d_insts = nullptr;
-    rvll_slot*   d_linslots = nullptr;
-    double*      d_layblob = nullptr;       // planets, insts, linslots, drift[4], tref back to back: staged into LDS by the kernels
-    int          form_override = 0;         // RVLL_FORM: 1 = tile kernel only, 2 = CU-wide kernel wherever it fits
-
-    // resident epoch table
-    int Ne = 0;
-    double*  d_t = nullptr;
-    double*  d_y = nullptr;
-    double*  d_s2 = nullptr;
-    int32_t* d_inst = nullptr;
-    double*  d_linpar = nullptr;
-    double   cte = 0.;
-    double   tmin = 0., tmax = 0.;              // range of the epoch times
-
-    // priors
-    bool have_priors = false;
-    rvll_prior* d_priors = nullptr;
-    int32_t* d_heavy = nullptr;
-    int n_heavy = 0;
-    std::vector<double*> d_tables;
-    std::vector<double> table_err;              // measured quintic-interpolant error per parameter (NaN: no table)
-    std::vector<int> table_direct;              // per parameter: evaluated by verified interpolation alone
-    bool all_direct = true;                     // every Beta / Gamma prior has a verified table: the slim prior stage applies
-    double slim_umax = 0.;                      // |logit q| range the slim stage takes (rvll_set_slim_table_range; default: the table's)
-    int* pin_defer = nullptr;                   // mapped pinned word the slim stage sets when it defers an element
-    int* pin_defer_dev = nullptr;
-    long long fused_pending = 0;                // rows of a one-launch cube -> log-L batch whose defer word has not been looked at yet
-
-    // batch buffers
-    long long cap = 0;
-    double*  d_theta = nullptr;
-    double*  d_cube = nullptr;
-    double*  d_logL2[kMaxLanes] = {};           // one log-L buffer per pipeline lane
-    int      logl_cur = 0;                      // lane the next device-resident launch uses
-    int      logl_last = 0;                     // lane the last launch used (download source)
-    bool     theta_async = false;               // theta was (re)written asynchronously on lane 0's stream
-    bool     pipelined = false;                 // launches alternate lanes: two are in flight, no kernel-end tail
-    int32_t* d_flags2[kMaxLanes] = {};          // per lane, like log-L
-
-    // pinned host staging for small transfers (scalar / small-batch callbacks)
-    static constexpr size_t kPinBytes = 1u << 20;
-    void* pin_in = nullptr;
-    void* pin_out = nullptr;
-    void* pin_in_dev = nullptr;      // device-visible aliases of the two pinned buffers (zero-copy path)
-    void* pin_out_dev = nullptr;
-
-    // large host batches (stream_host_batch): worker threads for the host's copies, pinned staging blocks, one event per block
-    CopyPool* pool = nullptr;
-    void* stage_in[kStageSlots] = {};
-    void* stage_out[kStageSlots] = {};
-    size_t stage_in_bytes = 0, stage_out_bytes = 0;
-    hipEvent_t stage_ev[kStageSlots] = {};      // a chunk's results are in its pinned block
-    hipEvent_t stage_up[kStageSlots] = {}, stage_done[kStageSlots] = {};   // ... its rows are on the device / its kernels have run
-    hipStream_t stream_up = nullptr, stream_down = nullptr;                // the two copy directions, beside lane 0's kernels (stream_reserve)
-
-    // scalar-call server (rvll_scalar_server): persistent one-workgroup kernel + host-coherent control block
-    rvll::ServerCtl* srv = nullptr;             // pinned, mapped, coherent
-    rvll::ServerCtl* srv_dev = nullptr;         // its device address
-    hipStream_t srv_stream = nullptr;
-    bool srv_enabled = false, srv_running = false, srv_dead = false;
-    unsigned long long srv_seq = 0;             // request numbers (low 32 bits travel)
-    unsigned long long srv_last = 0;            // the last request word that was answered
-    double*  d_srv_out = nullptr;               // device-local {logL, flags} the server's tile writes
-    unsigned long long srv_idle_ticks = 500000; // 5 ms of the 100 MHz constant clock
-
-    // device-resident slice-sampling walk (rvll_slice_walk)
-    long long walk_cap = 0;                     // rows
-    double *d_walk_u = nullptr, *d_walk_theta = nullptr, *d_walk_logl = nullptr, *d_walk_chol = nullptr;
-    int32_t* d_walk_wrapped = nullptr;
-    unsigned long long* d_walk_ncalls = nullptr;
-    int32_t *d_walk_steps = nullptr, *d_walk_wid = nullptr, *d_walk_start = nullptr;   // [walk_cap] each
-    int32_t *d_walk_cost = nullptr, *d_walk_order = nullptr;                            // [walk_cap] each (two-part walks)
-    int walk_spec = 4;                          // candidates a walker may evaluate ahead per iteration (rvll_set_walk_speculation)
-    long long walk_evaluated = 0;               // tile slots the last rvll_slice_walk evaluated (>= its ncalls)
-    unsigned long long walk_phase[6] = {};      // diagnostic build (make walktrace): 100 MHz ticks per phase, summed over workgroups; workgroups
-
-    // device-resident live set (rvll_live_*): nested sampling's live points, and the points that died, stay in HBM
-    long long live_n = 0, live_cap = 0;
-    double *d_live_u = nullptr, *d_live_theta = nullptr, *d_live_logl = nullptr;
-    int32_t* d_live_idx = nullptr;              // [2 * live_cap] order, then start rows, of the current step
-    double *d_live_mom = nullptr;               // scratch, mean, covariance of the whitening
-    long long dead_n = 0, dead_cap = 0;
-    double *d_dead_theta = nullptr, *d_dead_logl = nullptr;
-
-    hipEvent_t marks[2] = {nullptr, nullptr};   // rvll_dev_mark: HIP events on lane 0's stream
-
-    // geometry
-    int pb_override = 0;
-    std::unordered_map<long long, int> geo;     // batch size -> points per workgroup chosen for it
-    std::unordered_map<size_t, int> occ_by_lds; // dynamic LDS bytes -> resident workgroups per CU
-    int chunk_items = rvll::kTileWindow;
-    int n_cu = 256;
-
-    // multi-GPU
-    void* nccl_comm[kMaxLanes] = {};            // one communicator per lane (all but the first by ncclCommSplit)
-    int nranks = 1, rank = 0;
-    int nlanes = 1;
-    long long gather_cap = 0;
-    double* d_gather2[kMaxLanes] = {};
-    double *d_gather_host_in = nullptr, *d_gather_host_out = nullptr;   // rvll_allgather_host: grow-only staging
-    long long gather_host_cap = 0;              // in doubles
-    double* d_gather_theta = nullptr;           // [nranks * B_local, D] (rvll_allgather_theta)
-    long long gather_theta_cap = 0;             // in rows
-    int gather_last = 0;
-};
+using rvll::host::dev_free;
+using rvll::host::kDownloadStagedMin;
+using rvll::host::kDeadStagedMin;
 
 namespace {
 
@@ -316,7 +95,6 @@ void stream_free(rvll_handle* h);
 int download_rows(rvll_handle* h, void* dst, const void* src_dev, size_t bytes);
 // device -> pageable host copies from here on go through download_rows: arrays the caller makes per call (above glibc's mmap threshold
 // every array is a fresh mapping), and the dead points' one download per run into an array made for it
-constexpr size_t kDownloadStagedMin = 32u << 20, kDeadStagedMin = 8u << 20;
 
 int use_device(rvll_handle* h)
 {
@@ -714,7 +492,7 @@ int rvll_destroy(rvll_handle* h)
     if (h->srv) (void)server_stop(h);
     if (h->compute) (void)hipStreamSynchronize(h->compute);
     (void)sync_other_lanes(h);
-    for (auto& c : h->nccl_comm) if (c && g_rccl.lib) { (void)g_rccl.CommDestroy(c); c = nullptr; }
+    rvll::host::comm_release(h);
     free_priors(h);
     dev_free(h->d_theta); dev_free(h->d_cube);
     for (int l = 0; l < kMaxLanes; ++l) { dev_free(h->d_logL2[l]); dev_free(h->d_flags2[l]); dev_free(h->d_gather2[l]); }
@@ -725,7 +503,7 @@ int rvll_destroy(rvll_handle* h)
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     if (h->pin_defer) (void)hipHostFree(h->pin_defer);
     stream_free(h);
-    dev_free(h->d_walk_steps); dev_free(h->d_walk_wid); dev_free(h->d_walk_start);
+    dev_free(h->d_walk_steps); dev_free(h->d_walk_wid); dev_free(h->d_walk_start); dev_free(h->d_walk_cost); dev_free(h->d_walk_order);
     for (auto& e : h->marks) if (e) (void)hipEventDestroy(e);
     if (h->srv_stream) (void)hipStreamDestroy(h->srv_stream);
     if (h->srv) (void)hipHostFree(h->srv);
@@ -1776,527 +1554,6 @@ int rvll_prior_loglike_batch(rvll_handle* h, const double* cube, int64_t B,
     return rvll_dev_download(h, B, theta_out, logL, flags);
 }
 
-// ---- device-resident slice-sampling walk ---------------------------------------------------------------
-}   // extern "C"
-
-namespace {
-
-// device buffers of the walk for K rows (grown on demand)
-int walk_reserve(rvll_handle* h, int64_t K)
-{
-    const size_t D = (size_t)h->L.ndim;
-    int rc = rvll_dev_reserve(h, K + rvll::kMaxPointsPerBlock);   // scratch rows (one tile per workgroup): d_theta, log-L / flags of lane 0
-    if (rc) return rc;
-    rc = sync_other_lanes(h);
-    if (rc) return rc;
-    if (K > h->walk_cap || !h->d_walk_chol) {
-        HIP_TRY(hipStreamSynchronize(h->compute));
-        dev_free(h->d_walk_u); dev_free(h->d_walk_theta); dev_free(h->d_walk_logl);
-        dev_free(h->d_walk_steps); dev_free(h->d_walk_wid); dev_free(h->d_walk_start);
-        dev_free(h->d_walk_cost); dev_free(h->d_walk_order);
-        h->walk_cap = 0;
-        const size_t cap = (size_t)std::max<long long>(K, 1024);
-        HIP_TRY(hipMalloc(&h->d_walk_u, sizeof(double) * D * cap));
-        HIP_TRY(hipMalloc(&h->d_walk_theta, sizeof(double) * D * cap));
-        HIP_TRY(hipMalloc(&h->d_walk_logl, sizeof(double) * cap));
-        HIP_TRY(hipMalloc(&h->d_walk_steps, sizeof(int32_t) * cap));
-        HIP_TRY(hipMalloc(&h->d_walk_wid, sizeof(int32_t) * cap));
-        HIP_TRY(hipMalloc(&h->d_walk_start, sizeof(int32_t) * cap));
-        HIP_TRY(hipMalloc(&h->d_walk_cost, sizeof(int32_t) * cap));
-        HIP_TRY(hipMalloc(&h->d_walk_order, sizeof(int32_t) * cap));
-        if (!h->d_walk_chol) {
-            HIP_TRY(hipMalloc(&h->d_walk_chol, sizeof(double) * D * D));
-            HIP_TRY(hipMalloc(&h->d_walk_wrapped, sizeof(int32_t) * D));
-            HIP_TRY(hipMalloc(&h->d_walk_ncalls, kWalkWords * sizeof(unsigned long long)));   // calls used, tile slots evaluated, diagnostic bins
-        }
-        h->walk_cap = (long long)cap;
-    }
-    return RVLL_OK;
-}
-
-// The walk of the K rows resident in d_walk_u / d_walk_theta / d_walk_logl (chol and wrapped already uploaded): every
-// launch it takes — the first part, the rest (rows dealt to the workgroups by what they cost so far), the full-solver
-// finish of rows the slim kernel deferred — leaves the end points in those buffers.  Synchronises the compute stream.
-int walk_core(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t max_rounds, uint64_t seed,
-              int64_t walker_base, int64_t* ncalls)
-{
-    const size_t D = (size_t)h->L.ndim;
-    hipStream_t st = h->compute;
-    int rc;
-    HIP_TRY(hipMemsetAsync(h->d_walk_ncalls, 0, kWalkWords * sizeof(unsigned long long), st));
-    // the walk keeps per-walker state in LDS next to the tile's carve: shrink the group until both fit
-    auto walk_args = [&](long long n, rvll::LoglikeArgs* a) -> int {
-        int r = build_args(h, h->d_theta, h->d_logL2[0], h->d_flags2[0], n, a);
-        if (r) return r;
-        make_fused(h, h->d_cube, h->d_theta, a);
-        a->defer = nullptr;                            // deferrals are per walker here (steps_done), not per batch
-        auto window = [&](int pb) {                    // the tile's contribution window also holds 3 PB D doubles of the walk
-            int ch = std::min(h->chunk_items, std::max(rvll::kThreads, pb * h->Ne));
-            ch = std::max(ch, 3 * pb * a->D);
-            return (ch + 1) & ~1;
-        };
-        // Walker slots per workgroup: the walk's own phases cost a workgroup iteration the same whatever the number of
-        // slots, so more slots spread them thinner — as long as four workgroups still fit a compute unit's LDS.  Measured at
-        // cfg3 (profiles/r03_walk_forms.txt): 8: 1.54, 10: 1.58, 12: 1.58, 14: 1.53, 16: 1.47e8 calls/s inside the walk.
-        if (h->pb_override <= 0 && n >= 4096) {
-            a->PB = std::min(10, rvll::kMaxPointsPerBlock);
-            a->CH = window(a->PB);
-            while (a->PB > 1 && 4 * rvll::walk_lds_bytes(*a) > rvll::kCuLdsBudget) { a->PB -= 1; a->CH = window(a->PB); }
-        }
-        a->CH = window(a->PB);
-        while (a->PB > 1 && (rvll::walk_lds_bytes(*a) > 60 * 1024 || (long long)a->PB * a->D > 4 * rvll::kThreads)) {
-            a->PB -= 1;
-            a->CH = window(a->PB);
-        }
-        if (rvll::walk_lds_bytes(*a) > 64 * 1024 || (long long)a->PB * a->D > 4 * rvll::kThreads)
-            return fail(RVLL_E_UNSUPPORTED, "%d parameters exceed the walk kernel's LDS budget", a->D);
-        return RVLL_OK;
-    };
-    rvll::LoglikeArgs a;
-    rc = walk_args(K, &a);
-    if (rc) return rc;
-    // Slim walk (verified-table quantiles only, 4 waves per SIMD) when every Beta / Gamma prior has such a table;
-    // walkers it could not finish come back with steps_done < nsteps and are finished by the fat kernel below.
-    const bool slim = h->all_direct && !getenv("RVLL_WALK_FAT");
-    int spec = h->walk_spec;
-    if (const char* e = getenv("RVLL_WALK_SPEC")) spec = atoi(e);       // measurement switch (1: no speculation)
-    spec = std::max(1, std::min(spec, rvll::kMaxPointsPerBlock));
-    rvll::WalkArgs w{h->d_walk_u, h->d_walk_theta, h->d_walk_logl, h->d_walk_chol, h->d_walk_wrapped, (long long)K,
-                     nsteps, max_rounds, (unsigned long long)seed, lstar, h->d_walk_ncalls,
-                     h->d_walk_steps, nullptr, nullptr, (long long)walker_base, spec, h->d_walk_ncalls + 1,
-                     h->d_walk_ncalls + kWalkWords - 1, nullptr, nullptr, 0};
-    // no more workgroups than the chip holds at once; freed walker slots draw the remaining rows from a queue
-    // (RVLL_WALK_QUEUE, a measurement / test switch: 0 = one workgroup per PB rows, as many residency rounds as that
-    // takes; n > 0 = as many workgroups as n compute units hold, so that a small walk goes through the queue too)
-    const char* qenv = getenv("RVLL_WALK_QUEUE");
-    const int max_cus = qenv ? std::max(0, std::min(atoi(qenv), h->n_cu)) : h->n_cu;
-    // With more rows than walker slots a row handed out late still takes a whole walk — nsteps sequential moves — and the
-    // kernel ends in a drain (phase clock: mean workgroup life 7.2 ms of a 9.5 ms kernel at 16384 rows).  What a row costs
-    // per move is a property of where it walks, so the walk is launched in two parts: the first moves of every row through
-    // the queue (short rows: a fine grain), counting the candidates each one needs; then the rest in the "rows" form —
-    // every workgroup OWNS an equal share of the rows by that cost and interleaves them over its walker slots, so all rows
-    // of the launch end together (rvll_walk.hip, slice_walk_rows_kernel).  Results are those of one launch (the moves of
-    // a row do not care which launch makes them).  RVLL_WALK_PARTS=1: one launch (measurement / test switch).
-    // RVLL_WALK_ROWS=1 selects the rows form; the DEFAULT is the second part through the queue as well, most expensive
-    // rows first (round 2's form): measured on bench.py's nested run (profiles/r03_walk_forms.txt) the rows form balances
-    // the workgroups as designed — and is 7 % slower (1.38 vs 1.48e8 calls/s inside the walk): with every slot always
-    // holding a walker no tile slot is ever free for candidates ahead, and the kernel is bound by what a workgroup's
-    // iteration costs (2600 vector instructions per candidate against the batch kernel's 1990, VALUs busy 75 %), not by
-    // its tail.  Kept, tested bit-identical, for walks whose rows differ more than cfg3's.
-    const long long resident = max_cus > 0 ? rvll::slice_walk_resident_blocks(a, !slim, max_cus) : 0;
-    const char* penv = getenv("RVLL_WALK_PARTS");
-    const bool two_parts = resident > 0 && K > resident * a.PB && nsteps >= 8 && !(penv && atoi(penv) == 1);
-    const char* renv = getenv("RVLL_WALK_ROWS");
-    const bool rows_form = renv && atoi(renv) >= 1 && 3LL * a.PB * a.D <= a.CH;      // (the rows kernels park their candidates in the tile's window)
-    const int rows_wide = renv && atoi(renv) == 2 ? rvll::kCuThreads : renv && atoi(renv) == 3 ? 512 : 0;   // 2: one 1024-thread workgroup per CU, 3: two of 512
-    if (two_parts) {
-        w.nsteps = std::max(1, rows_form ? nsteps / 8 : nsteps / 4);
-        if (const char* e = getenv("RVLL_WALK_FIRST")) w.nsteps = std::max(1, std::min(nsteps - 1, atoi(e)));   // measurement switch
-        w.cost = h->d_walk_cost;
-    }
-    HIP_TRY(rvll::launch_slice_walk(a, w, !slim, max_cus, st));
-    if (two_parts) {
-        const int first = w.nsteps;
-        std::vector<int32_t> cost((size_t)K), done((size_t)K), order((size_t)K);
-        HIP_TRY(hipMemcpyAsync(cost.data(), h->d_walk_cost, sizeof(int32_t) * (size_t)K, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(done.data(), h->d_walk_steps, sizeof(int32_t) * (size_t)K, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        // counting sort, most expensive first; rows that did not complete the first part (deferred) go last
-        const int32_t cmax = std::min<int32_t>(first * max_rounds, 1 << 16);
-        std::vector<int32_t> count((size_t)cmax + 2, 0);
-        auto key = [&](int64_t i) { return done[(size_t)i] >= first ? std::min(std::max(cost[(size_t)i], 0), cmax) + 1 : 0; };
-        for (int64_t i = 0; i < K; ++i) ++count[(size_t)key(i)];
-        const int32_t nkey0 = count[0];                  // rows the first part deferred: left to the full-solver pass below
-        if (getenv("RVLL_WALK_COST_DUMP")) {
-            std::vector<int32_t> cs(cost);
-            std::sort(cs.begin(), cs.end());
-            double sum = 0; for (int32_t c : cs) sum += c;
-            fprintf(stderr, "[walk cost, first %d moves] K=%lld mean %.1f  p50 %d  p90 %d  p99 %d  p99.9 %d  max %d\n", first, (long long)K,
-                    sum / (double)K, cs[(size_t)(K / 2)], cs[(size_t)(K * 9 / 10)], cs[(size_t)(K * 99 / 100)], cs[(size_t)(K * 999 / 1000)], cs.back());
-        }
-        int32_t pos = 0;
-        for (int32_t c = cmax + 1; c >= 0; --c) { const int32_t n_c = count[(size_t)c]; count[(size_t)c] = pos; pos += n_c; }
-        for (int64_t i = 0; i < K; ++i) order[(size_t)count[(size_t)key(i)]++] = (int32_t)i;
-        const int64_t K2 = K - nkey0;
-        w.nsteps = nsteps;
-        w.cost = nullptr;
-        w.step_start = h->d_walk_steps;    // every row resumes where the first part left it (read before it is rewritten)
-        if (K2 > 0 && rows_form) {
-            // as many workgroups as the chip holds, every one an equal share of the rows (snake deal of the sorted order,
-            // in the kernel); a share that does not fit the kernel's LDS goes in several launches, one after the other.
-            // RVLL_WALK_ROWS=2: the CU-wide form — one 1024-thread workgroup per compute unit with as many walker slots
-            // (<= 64) as its LDS holds next to the parked rows, the tile in its CU-wide form; 3: two 512-thread workgroups
-            rvll::LoglikeArgs ar = a;
-            int64_t G = std::min<int64_t>((K2 + a.PB - 1) / a.PB, resident);
-            // (the wide forms exist for the slim stage only: the full-solver instantiation does not fit 128 VGPRs unspilled)
-            const int nt = (rows_wide && slim) ? rows_wide : rvll::kThreads;
-            const bool cu_wide = nt != rvll::kThreads;
-            const size_t wide_budget = nt == rvll::kCuThreads ? rvll::kCuLdsBudget : rvll::kCuLdsBudget / 2;
-            if (cu_wide) {
-                G = std::min<int64_t>((int64_t)(max_cus > 0 ? max_cus : h->n_cu) * (rvll::kCuThreads / nt), K2);
-                const int64_t rows = (K2 + G - 1) / G;
-                int slots = (int)std::min<int64_t>(rvll::kWave, rows);
-                auto fits = [&](int sl) {
-                    ar.PB = sl;
-                    ar.CH = (std::max(sl * h->Ne, 3 * sl * h->L.ndim) + 1) & ~1;
-                    return rvll::walk_rows_lds_bytes(ar, (int)rows) <= wide_budget;
-                };
-                while (slots > 1 && !fits(slots)) --slots;
-                if (!fits(slots)) return fail(RVLL_E_UNSUPPORTED, "the wide walk does not fit %lld rows per workgroup", (long long)rows);
-                rc = rvll_dev_reserve(h, std::max<int64_t>(K, G * slots) + rvll::kMaxPointsPerBlock);   // the tiles' scratch rows
-                if (rc) return rc;
-                ar.theta = h->d_theta; ar.logL = h->d_logL2[0]; ar.flags = h->d_flags2[0];
-                make_fused(h, h->d_cube, h->d_theta, &ar);
-                ar.defer = nullptr;
-            }
-            int64_t rmax = 1;
-            const size_t budget = cu_wide ? wide_budget : (size_t)60 * 1024;
-            while (rmax < 4096 && rvll::walk_rows_lds_bytes(ar, (int)rmax + 1) <= budget) ++rmax;
-            const int64_t chunk = G * rmax;
-            HIP_TRY(hipMemcpyAsync(h->d_walk_order, order.data(), sizeof(int32_t) * (size_t)K2, hipMemcpyHostToDevice, st));
-            for (int64_t lo = 0; lo < K2; lo += chunk) {
-                const int64_t n = std::min<int64_t>(chunk, K2 - lo);
-                rvll::WalkArgs wr = w;
-                wr.K = n;
-                wr.order = h->d_walk_order + lo;
-                const int64_t g = std::min<int64_t>(G, (n + ar.PB - 1) / ar.PB);
-                wr.rows_per_wg = (int)((n + g - 1) / g);
-                HIP_TRY(rvll::launch_slice_walk_rows(ar, wr, !slim, (int)g, nt, st));
-            }
-            HIP_TRY(hipStreamSynchronize(st)); // `order` goes out of scope
-        } else if (K2 > 0) {
-            {
-                // the workgroups' first rows: deal the G * PB most expensive ones round the workgroups like cards, so that
-                // every workgroup starts with one of the G longest, one of the next G, ... — eight long rows in one
-                // workgroup would leave it no free tile slot to evaluate candidates ahead with, and they are the critical path
-                const int64_t G = std::min<int64_t>((K2 + a.PB - 1) / a.PB, resident), first_rows = std::min<int64_t>(G * a.PB, K2);
-                std::vector<int32_t> dealt((size_t)first_rows);
-                int64_t k = 0;
-                for (int64_t pl = 0; pl < a.PB; ++pl)
-                    for (int64_t b = 0; b < G; ++b) {
-                        const int64_t slot = b * a.PB + pl;
-                        if (slot < first_rows && k < first_rows) dealt[(size_t)slot] = order[(size_t)k++];
-                    }
-                std::copy(dealt.begin(), dealt.end(), order.begin());
-            }
-            HIP_TRY(hipMemcpyAsync(h->d_walk_order, order.data(), sizeof(int32_t) * (size_t)K2, hipMemcpyHostToDevice, st));
-            HIP_TRY(hipMemsetAsync(h->d_walk_ncalls + kWalkWords - 1, 0, sizeof(unsigned long long), st));   // the queue; the counts go on
-            w.K = K2;
-            w.order = h->d_walk_order;
-            HIP_TRY(rvll::launch_slice_walk(a, w, !slim, max_cus, st));
-            HIP_TRY(hipStreamSynchronize(st)); // `order` goes out of scope
-        }
-        w.K = K;
-        w.order = nullptr;
-        w.step_start = nullptr;
-    }
-    unsigned long long evaluated[kWalkWords] = {};
-    h->walk_evaluated = 0;
-    std::vector<int32_t> steps(slim ? (size_t)K : 0);
-    HIP_TRY(hipMemcpyAsync(evaluated, h->d_walk_ncalls, sizeof evaluated, hipMemcpyDeviceToHost, st));
-    if (slim) HIP_TRY(hipMemcpyAsync(steps.data(), h->d_walk_steps, sizeof(int32_t) * (size_t)K, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    long long total = (long long)evaluated[0];
-    h->walk_evaluated = (long long)evaluated[1];
-    for (int k = 0; k < 6; ++k) h->walk_phase[k] = evaluated[2 + k];
-    if (getenv("RVLL_WALK_TILE_DUMP") && evaluated[6])       // diagnostic build: the tile's own phases inside the walk (100 MHz ticks)
-        fprintf(stderr, "[walk tile phases, summed over %llu workgroups] stage %llu  decode %llu  items %llu  reduce+write %llu ticks\n",
-                evaluated[6], evaluated[8], evaluated[9], evaluated[10], evaluated[11]);
-    if (slim) {
-        std::vector<int32_t> ids, start;
-        for (int64_t i = 0; i < K; ++i)
-            if (steps[(size_t)i] < nsteps) { ids.push_back((int32_t)i); start.push_back(steps[(size_t)i]); }
-        if (!ids.empty()) {
-            // finish the interrupted walkers with the full solvers inline: same seed, same walker index in the
-            // random-number counters, resumed at the start of the move that was interrupted.  Rare: the rows travel
-            // through the host (the whole buffers down, the interrupted rows compacted to their front, walked, and
-            // everything put back)
-            const size_t M = ids.size();
-            std::vector<double> hu(D * (size_t)K), hth(D * (size_t)K), hl((size_t)K), su(M * D), sth(M * D), sl(M);
-            HIP_TRY(hipMemcpyAsync(hu.data(), h->d_walk_u, sizeof(double) * D * (size_t)K, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(hth.data(), h->d_walk_theta, sizeof(double) * D * (size_t)K, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(hl.data(), h->d_walk_logl, sizeof(double) * (size_t)K, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            for (size_t j = 0; j < M; ++j) {
-                memcpy(&su[j * D], &hu[(size_t)ids[j] * D], sizeof(double) * D);
-                memcpy(&sth[j * D], &hth[(size_t)ids[j] * D], sizeof(double) * D);
-                sl[j] = hl[(size_t)ids[j]];
-            }
-            HIP_TRY(hipMemcpyAsync(h->d_walk_u, su.data(), sizeof(double) * D * M, hipMemcpyHostToDevice, st));
-            HIP_TRY(hipMemcpyAsync(h->d_walk_theta, sth.data(), sizeof(double) * D * M, hipMemcpyHostToDevice, st));
-            HIP_TRY(hipMemcpyAsync(h->d_walk_logl, sl.data(), sizeof(double) * M, hipMemcpyHostToDevice, st));
-            HIP_TRY(hipMemcpyAsync(h->d_walk_wid, ids.data(), sizeof(int32_t) * M, hipMemcpyHostToDevice, st));
-            HIP_TRY(hipMemcpyAsync(h->d_walk_start, start.data(), sizeof(int32_t) * M, hipMemcpyHostToDevice, st));
-            HIP_TRY(hipMemsetAsync(h->d_walk_ncalls, 0, kWalkWords * sizeof(unsigned long long), st));
-            rvll::LoglikeArgs a2;
-            rc = walk_args((long long)M, &a2);
-            if (rc) return rc;
-            rvll::WalkArgs w2 = w;
-            w2.K = (long long)M;
-            w2.walker_id = h->d_walk_wid;
-            w2.step_start = h->d_walk_start;
-            HIP_TRY(rvll::launch_slice_walk(a2, w2, true, max_cus, st));
-            HIP_TRY(hipMemcpyAsync(su.data(), h->d_walk_u, sizeof(double) * D * M, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(sth.data(), h->d_walk_theta, sizeof(double) * D * M, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(sl.data(), h->d_walk_logl, sizeof(double) * M, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(evaluated, h->d_walk_ncalls, sizeof evaluated, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            total += (long long)evaluated[0];
-            h->walk_evaluated += (long long)evaluated[1];
-            for (int k = 0; k < 6; ++k) h->walk_phase[k] += evaluated[2 + k];
-            for (size_t j = 0; j < M; ++j) {
-                memcpy(&hu[(size_t)ids[j] * D], &su[j * D], sizeof(double) * D);
-                memcpy(&hth[(size_t)ids[j] * D], &sth[j * D], sizeof(double) * D);
-                hl[(size_t)ids[j]] = sl[j];
-            }
-            HIP_TRY(hipMemcpyAsync(h->d_walk_u, hu.data(), sizeof(double) * D * (size_t)K, hipMemcpyHostToDevice, st));
-            HIP_TRY(hipMemcpyAsync(h->d_walk_theta, hth.data(), sizeof(double) * D * (size_t)K, hipMemcpyHostToDevice, st));
-            HIP_TRY(hipMemcpyAsync(h->d_walk_logl, hl.data(), sizeof(double) * (size_t)K, hipMemcpyHostToDevice, st));
-            HIP_TRY(hipStreamSynchronize(st));
-        }
-    }
-    if (ncalls) *ncalls = (int64_t)total;
-    h->theta_async = false;
-    return RVLL_OK;
-}
-
-int walk_check_args(rvll_handle* h, int64_t K, int32_t nsteps, int32_t max_rounds, int64_t walker_base)
-{
-    if (!h->have_priors) return fail(RVLL_E_NOPRIORS, "rvll_set_priors has not been called");
-    if (K < 0 || nsteps < 0) return fail(RVLL_E_INVALID, "negative size");
-    if (max_rounds < 1 || max_rounds > 4096 || nsteps >= (1 << 18) || K >= (1LL << 31) || walker_base < 0 ||
-        walker_base + K >= (1LL << 32))
-        return fail(RVLL_E_INVALID, "nsteps / max_rounds / K / walker_base out of range");
-    if (h->L.ndim < 1) return fail(RVLL_E_INVALID, "no free parameter to walk in");
-    return RVLL_OK;
-}
-
-int walk_upload_frame(rvll_handle* h, const double* chol, const int32_t* wrapped)
-{
-    const size_t D = (size_t)h->L.ndim;
-    std::vector<int32_t> wr(D, 0);
-    if (wrapped) for (size_t k = 0; k < D; ++k) wr[k] = wrapped[k] != 0;
-    HIP_TRY(hipMemcpyAsync(h->d_walk_chol, chol, sizeof(double) * D * D, hipMemcpyHostToDevice, h->compute));
-    HIP_TRY(hipMemcpyAsync(h->d_walk_wrapped, wr.data(), sizeof(int32_t) * D, hipMemcpyHostToDevice, h->compute));
-    HIP_TRY(hipStreamSynchronize(h->compute));         // wr (and pageable sources) may go out of scope
-    return RVLL_OK;
-}
-
-}  // namespace
-
-extern "C" {
-
-int rvll_slice_walk(rvll_handle* h, double* cube, double* theta, double* logl, int64_t K, double lstar,
-                    const double* chol, const int32_t* wrapped, int32_t nsteps, int32_t max_rounds,
-                    uint64_t seed, int64_t walker_base, int64_t* ncalls)
-{
-    int rc = use_device(h);
-    if (rc) return rc;
-    if (ncalls) *ncalls = 0;
-    rc = walk_check_args(h, K, nsteps, max_rounds, walker_base);
-    if (rc) return rc;
-    if (K == 0 || nsteps == 0) return RVLL_OK;
-    if (!cube || !theta || !logl || !chol) return fail(RVLL_E_INVALID, "null buffer");
-    const size_t D = (size_t)h->L.ndim;
-    rc = walk_reserve(h, K);
-    if (rc) return rc;
-    hipStream_t st = h->compute;
-    HIP_TRY(hipMemcpyAsync(h->d_walk_u, cube, sizeof(double) * D * (size_t)K, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(h->d_walk_theta, theta, sizeof(double) * D * (size_t)K, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(h->d_walk_logl, logl, sizeof(double) * (size_t)K, hipMemcpyHostToDevice, st));
-    rc = walk_upload_frame(h, chol, wrapped);
-    if (rc) return rc;
-    rc = walk_core(h, K, lstar, nsteps, max_rounds, seed, walker_base, ncalls);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(cube, h->d_walk_u, sizeof(double) * D * (size_t)K, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(theta, h->d_walk_theta, sizeof(double) * D * (size_t)K, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(logl, h->d_walk_logl, sizeof(double) * (size_t)K, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    return RVLL_OK;
-}
-
-// ---- nested sampling with the live points resident on the device -------------------------------------------
-int rvll_live_init(rvll_handle* h, const double* cube, int64_t N, double* logl_out)
-{
-    int rc = use_device(h);
-    if (rc) return rc;
-    if (!h->have_priors) return fail(RVLL_E_NOPRIORS, "rvll_set_priors has not been called");
-    if (N < 1 || N >= (1LL << 31) || !cube) return fail(RVLL_E_INVALID, "rvll_live_init: bad arguments");
-    const size_t D = (size_t)std::max(1, h->L.ndim);
-    rc = rvll_dev_upload_cube(h, cube, N);
-    if (rc) return rc;
-    rc = rvll_dev_prior_loglike(h, N);
-    if (rc) return rc;
-    rc = rvll_dev_sync(h);
-    if (rc) return rc;
-    rc = use_device(h);                                  // (elements the table-only prior stage handed over are redone here)
-    if (rc) return rc;
-    if (N > h->live_cap) {
-        dev_free(h->d_live_u); dev_free(h->d_live_theta); dev_free(h->d_live_logl); dev_free(h->d_live_idx);
-        h->live_cap = 0;
-        HIP_TRY(hipMalloc(&h->d_live_u, sizeof(double) * D * (size_t)N));
-        HIP_TRY(hipMalloc(&h->d_live_theta, sizeof(double) * D * (size_t)N));
-        HIP_TRY(hipMalloc(&h->d_live_logl, sizeof(double) * (size_t)N));
-        HIP_TRY(hipMalloc(&h->d_live_idx, sizeof(int32_t) * 2 * (size_t)N));
-        h->live_cap = N;
-    }
-    if (!h->d_live_mom) HIP_TRY(hipMalloc(&h->d_live_mom, sizeof(double) * (rvll::moments_scratch_doubles((int)D) + D + D * D)));
-    hipStream_t st = h->compute;
-    HIP_TRY(hipMemcpyAsync(h->d_live_u, h->d_cube, sizeof(double) * D * (size_t)N, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipMemcpyAsync(h->d_live_theta, h->d_theta, sizeof(double) * D * (size_t)N, hipMemcpyDeviceToDevice, st));
-    HIP_TRY(hipMemcpyAsync(h->d_live_logl, h->d_logL2[h->logl_last], sizeof(double) * (size_t)N, hipMemcpyDeviceToDevice, st));
-    if (logl_out) HIP_TRY(hipMemcpyAsync(logl_out, h->d_live_logl, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    h->live_n = N;
-    h->dead_n = 0;
-    return RVLL_OK;
-}
-
-int rvll_live_step(rvll_handle* h, const int32_t* order, int64_t kdead, const int32_t* start, double lstar,
-                   const double* chol, const int32_t* wrapped, int32_t nsteps, int32_t max_rounds, uint64_t seed,
-                   int64_t walker_base, int64_t* ncalls, double* logl_new, double* chol_out)
-{
-    int rc = use_device(h);
-    if (rc) return rc;
-    if (ncalls) *ncalls = 0;
-    const int64_t N = h->live_n;
-    if (N < 1) return fail(RVLL_E_INVALID, "rvll_live_init has not been called");
-    if (!order || !start || !logl_new || kdead < 1 || kdead >= N) return fail(RVLL_E_INVALID, "rvll_live_step: bad arguments");
-    rc = walk_check_args(h, kdead, nsteps, max_rounds, walker_base);
-    if (rc) return rc;
-    for (int64_t i = 0; i < N; ++i)
-        if (order[i] < 0 || order[i] >= N) return fail(RVLL_E_INVALID, "rvll_live_step: order[%lld] out of range", (long long)i);
-    for (int64_t i = 0; i < kdead; ++i)
-        if (start[i] < 0 || start[i] >= N) return fail(RVLL_E_INVALID, "rvll_live_step: start[%lld] out of range", (long long)i);
-    const size_t D = (size_t)h->L.ndim;
-    const int Di = h->L.ndim;
-    rc = walk_reserve(h, kdead);
-    if (rc) return rc;
-    hipStream_t st = h->compute;
-    int32_t* d_order = h->d_live_idx;
-    int32_t* d_start = h->d_live_idx + h->live_cap;
-    HIP_TRY(hipMemcpyAsync(d_order, order, sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_start, start, sizeof(int32_t) * (size_t)kdead, hipMemcpyHostToDevice, st));
-    // the points that die (rows order[0 .. kdead)) go to the dead store before their rows are overwritten
-    if (h->dead_n + kdead > h->dead_cap) {
-        const long long cap = std::max<long long>(2 * h->dead_cap, h->dead_n + 4 * kdead);
-        double *nt = nullptr, *nl = nullptr;
-        HIP_TRY(hipMalloc(&nt, sizeof(double) * D * (size_t)cap));
-        HIP_TRY(hipMalloc(&nl, sizeof(double) * (size_t)cap));
-        if (h->dead_n) {
-            HIP_TRY(hipMemcpyAsync(nt, h->d_dead_theta, sizeof(double) * D * (size_t)h->dead_n, hipMemcpyDeviceToDevice, st));
-            HIP_TRY(hipMemcpyAsync(nl, h->d_dead_logl, sizeof(double) * (size_t)h->dead_n, hipMemcpyDeviceToDevice, st));
-            HIP_TRY(hipStreamSynchronize(st));
-        }
-        dev_free(h->d_dead_theta); dev_free(h->d_dead_logl);
-        h->d_dead_theta = nt; h->d_dead_logl = nl; h->dead_cap = cap;
-    }
-    HIP_TRY(rvll::launch_gather_rows(h->d_live_theta, d_order, kdead, Di, h->d_dead_theta + (size_t)h->dead_n * D, st));
-    HIP_TRY(rvll::launch_gather_rows(h->d_live_logl, d_order, kdead, 1, h->d_dead_logl + h->dead_n, st));
-    h->dead_n += kdead;
-    // whitening: the caller's factor, or the covariance of the surviving rows order[kdead .. N) summed on the device (in a
-    // fixed order) and factored here (19 x 19: host arithmetic; + 1e-14 on the diagonal as evidence_amd/nested.py adds)
-    std::vector<double> factor(D * D, 0.);
-    if (chol) {
-        memcpy(factor.data(), chol, sizeof(double) * D * D);
-    } else {
-        double* scratch = h->d_live_mom;
-        double* d_mean = scratch + rvll::moments_scratch_doubles(Di);
-        double* d_cov = d_mean + D;
-        HIP_TRY(rvll::launch_moments(h->d_live_u, d_order + kdead, N - kdead, Di, scratch, d_mean, d_cov, st));
-        std::vector<double> cov(D * D);
-        HIP_TRY(hipMemcpyAsync(cov.data(), d_cov, sizeof(double) * D * D, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        for (size_t j = 0; j < D; ++j) {                 // Cholesky - Banachiewicz, lower triangle
-            for (size_t l = 0; l <= j; ++l) {
-                double sum = cov[j * D + l] + (j == l ? 1e-14 : 0.);
-                for (size_t m = 0; m < l; ++m) sum -= factor[j * D + m] * factor[l * D + m];
-                if (j == l) {
-                    if (!(sum > 0.)) return fail(RVLL_E_INVALID, "rvll_live_step: the live points' covariance is not positive definite");
-                    factor[j * D + j] = std::sqrt(sum);
-                } else {
-                    factor[j * D + l] = sum / factor[l * D + l];
-                }
-            }
-        }
-    }
-    if (chol_out) memcpy(chol_out, factor.data(), sizeof(double) * D * D);
-    // the walkers start from rows start[0 .. kdead)
-    HIP_TRY(rvll::launch_gather_rows(h->d_live_u, d_start, kdead, Di, h->d_walk_u, st));
-    HIP_TRY(rvll::launch_gather_rows(h->d_live_theta, d_start, kdead, Di, h->d_walk_theta, st));
-    HIP_TRY(rvll::launch_gather_rows(h->d_live_logl, d_start, kdead, 1, h->d_walk_logl, st));
-    rc = walk_upload_frame(h, factor.data(), wrapped);
-    if (rc) return rc;
-    rc = walk_core(h, kdead, lstar, nsteps, max_rounds, seed, walker_base, ncalls);
-    if (rc) return rc;
-    // ... and their end points replace the dead rows
-    HIP_TRY(rvll::launch_scatter_rows(h->d_walk_u, d_order, kdead, Di, h->d_live_u, st));
-    HIP_TRY(rvll::launch_scatter_rows(h->d_walk_theta, d_order, kdead, Di, h->d_live_theta, st));
-    HIP_TRY(rvll::launch_scatter_rows(h->d_walk_logl, d_order, kdead, 1, h->d_live_logl, st));
-    HIP_TRY(hipMemcpyAsync(logl_new, h->d_walk_logl, sizeof(double) * (size_t)kdead, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    return RVLL_OK;
-}
-
-int rvll_live_get(rvll_handle* h, double* cube, double* theta, double* logl)
-{
-    int rc = use_device(h);
-    if (rc) return rc;
-    if (h->live_n < 1) return fail(RVLL_E_INVALID, "rvll_live_init has not been called");
-    const size_t D = (size_t)h->L.ndim, N = (size_t)h->live_n;
-    hipStream_t st = h->compute;
-    const bool staged = sizeof(double) * D * N >= kDownloadStagedMin;
-    if (cube && staged) { rc = download_rows(h, cube, h->d_live_u, sizeof(double) * D * N); if (rc) return rc; }
-    else if (cube) HIP_TRY(hipMemcpyAsync(cube, h->d_live_u, sizeof(double) * D * N, hipMemcpyDeviceToHost, st));
-    if (theta && staged) { rc = download_rows(h, theta, h->d_live_theta, sizeof(double) * D * N); if (rc) return rc; }
-    else if (theta) HIP_TRY(hipMemcpyAsync(theta, h->d_live_theta, sizeof(double) * D * N, hipMemcpyDeviceToHost, st));
-    if (logl) HIP_TRY(hipMemcpyAsync(logl, h->d_live_logl, sizeof(double) * N, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    return RVLL_OK;
-}
-
-int rvll_live_dead(rvll_handle* h, int64_t* n_dead, double* theta, double* logl)
-{
-    int rc = use_device(h);
-    if (rc) return rc;
-    if (!n_dead) return fail(RVLL_E_INVALID, "n_dead is null");
-    const int64_t have = h->dead_n, want = (theta || logl) ? std::min<int64_t>(*n_dead, have) : 0;
-    *n_dead = have;
-    const size_t D = (size_t)h->L.ndim;
-    hipStream_t st = h->compute;
-    if (want > 0 && theta && sizeof(double) * D * (size_t)want >= kDeadStagedMin) {
-        rc = download_rows(h, theta, h->d_dead_theta, sizeof(double) * D * (size_t)want);
-        if (rc) return rc;
-    } else if (want > 0 && theta) {
-        HIP_TRY(hipMemcpyAsync(theta, h->d_dead_theta, sizeof(double) * D * (size_t)want, hipMemcpyDeviceToHost, st));
-    }
-    if (want > 0 && logl) HIP_TRY(hipMemcpyAsync(logl, h->d_dead_logl, sizeof(double) * (size_t)want, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    return RVLL_OK;
-}
-
-int rvll_set_walk_speculation(rvll_handle* h, int32_t max_ahead)
-{
-    if (!h) return fail(RVLL_E_INVALID, "null handle");
-    if (max_ahead < 1 || max_ahead > rvll::kMaxPointsPerBlock)
-        return fail(RVLL_E_INVALID, "max_ahead must be in [1, %d]", rvll::kMaxPointsPerBlock);
-    h->walk_spec = max_ahead;
-    return RVLL_OK;
-}
-
-int rvll_slice_walk_evaluated(rvll_handle* h, int64_t* evaluated)
-{
-    if (!h || !evaluated) return fail(RVLL_E_INVALID, "null argument");
-    *evaluated = h->walk_evaluated;
-    return RVLL_OK;
-}
-
-int rvll_slice_walk_phases(rvll_handle* h, uint64_t out[6])
-{
-    if (!h || !out) return fail(RVLL_E_INVALID, "null argument");
-    for (int k = 0; k < 6; ++k) out[k] = h->walk_phase[k];
-    return RVLL_OK;
-}
 
 int rvll_set_slim_table_range(rvll_handle* h, double umax)
 {
@@ -2358,222 +1615,18 @@ int rvll_debug_eval(rvll_handle* h, int32_t op, const double* x, const double* y
     return status;
 }
 
-// ---- multi-GPU ---------------------------------------------------------------------
-int rvll_comm_unique_id(unsigned char id[RVLL_COMM_ID_BYTES])
-{
-    if (!id) return fail(RVLL_E_INVALID, "id is null");
-    int rc = rccl_load();
-    if (rc) return rc;
-    Id128 u;
-    memset(&u, 0, sizeof u);
-    RCCL_TRY(g_rccl.GetUniqueId(&u));
-    memcpy(id, u.bytes, RVLL_COMM_ID_BYTES);
-    return RVLL_OK;
-}
-
-int rvll_runtime_info(char* buf, int32_t buflen)
-{
-    if (!buf || buflen < 1) return fail(RVLL_E_INVALID, "bad buffer");
-    int hip_rt = 0, hip_drv = 0;
-    (void)hipRuntimeGetVersion(&hip_rt);
-    (void)hipDriverGetVersion(&hip_drv);
-    snprintf(buf, (size_t)buflen,
-             "{\"hip_runtime_version\": %d, \"hip_driver_version\": %d, \"libamdhip64\": \"%s\", "
-             "\"librccl\": \"%s\", \"rccl_version\": %d, \"librvll\": \"%s\"}",
-             hip_rt, hip_drv, lib_path_of(reinterpret_cast<const void*>(&hipGetDeviceCount)).c_str(),
-             g_rccl.lib ? g_rccl_path.c_str() : "not loaded", g_rccl_version,
-             lib_path_of(reinterpret_cast<const void*>(&rvll_runtime_info)).c_str());
-    return RVLL_OK;
-}
-
-// One communicator, one pipeline lane: the gather of a step runs in-stream behind its kernel.  Further lanes are
-// added by rvll_comm_add_lanes once the caller has seen a gathered step complete on this one.
-int rvll_comm_init(rvll_handle* h, const unsigned char id[RVLL_COMM_ID_BYTES], int32_t nranks, int32_t rank)
-{
-    int rc = use_device(h);
-    if (rc) return rc;
-    if (!id || nranks < 1 || rank < 0 || rank >= nranks) return fail(RVLL_E_INVALID, "bad comm arguments");
-    rc = rccl_load();
-    if (rc) return rc;
-    rc = rvll_comm_destroy(h);
-    if (rc) return rc;
-    Id128 u;
-    memcpy(u.bytes, id, RVLL_COMM_ID_BYTES);
-    RCCL_TRY(g_rccl.CommInitRank(&h->nccl_comm[0], nranks, u, rank));
-    h->nranks = nranks;
-    h->rank = rank;
-    h->nlanes = 1;
-    h->logl_cur = 0;
-    return RVLL_OK;
-}
-
-// Further pipeline lanes: one communicator each (collectives of ONE communicator must not run concurrently on two
-// streams), derived collectively from the first by ncclCommSplit — every rank must make this call.  Returns in
-// *have how many lanes THIS rank now holds (<= want); the ranks must then agree on the minimum over all of them
-// (out of band) and call rvll_comm_set_lanes with it, so that every rank cycles through the same communicators:
-// a rank with fewer lanes than its peers would issue its gathers on mismatched communicators and hang them all.
-int rvll_comm_add_lanes(rvll_handle* h, int32_t want, int32_t* have)
-{
-    int rc = use_device(h);
-    if (rc) return rc;
-    if (!h->nccl_comm[0]) return fail(RVLL_E_RCCL, "rvll_comm_init has not been called");
-    want = std::max(1, std::min(kMaxLanes, (int)want));
-    int got = 1;
-    for (int l = 1; l < kMaxLanes; ++l) if (h->nccl_comm[l]) got = l + 1; else break;
-    for (int l = got; l < want; ++l) {
-        if (!g_rccl.CommSplit || g_rccl.CommSplit(h->nccl_comm[0], 0, h->rank, &h->nccl_comm[l], nullptr) != 0 || !h->nccl_comm[l]) {
-            h->nccl_comm[l] = nullptr;
-            break;
-        }
-        got = l + 1;
-    }
-    if (have) *have = got;
-    return RVLL_OK;
-}
-
-int rvll_comm_set_lanes(rvll_handle* h, int32_t nlanes)
-{
-    int rc = use_device(h);
-    if (rc) return rc;
-    if (!h->nccl_comm[0]) return fail(RVLL_E_RCCL, "rvll_comm_init has not been called");
-    if (nlanes < 1 || nlanes > kMaxLanes) return fail(RVLL_E_INVALID, "nlanes out of range");
-    for (int l = 0; l < nlanes; ++l)
-        if (!h->nccl_comm[l]) return fail(RVLL_E_INVALID, "lane %d has no communicator on this rank", l);
-    HIP_TRY(hipStreamSynchronize(h->compute));
-    rc = sync_other_lanes(h);
-    if (rc) return rc;
-    if (nlanes > h->nlanes && h->gather_cap > 0) {          // gather buffers of the new lanes
-        for (int l = h->nlanes; l < nlanes; ++l)
-            if (!h->d_gather2[l]) HIP_TRY(hipMalloc(&h->d_gather2[l], sizeof(double) * (size_t)h->gather_cap));
-    }
-    h->nlanes = nlanes;
-    h->logl_cur = 0;
-    return RVLL_OK;
-}
-
-// One multi-GPU step is  rvll_dev_loglike(B_local) ; rvll_allgather_logl(B_local).  Steps alternate between two
-// pipeline LANES, each with its own stream, communicator, log-L and gather buffer: the gather of step k runs
-// in-stream right behind kernel k on lane (k mod 2) while kernel k+1 runs on the other lane, so collective
-// latency hides behind compute without any cross-stream event (measured on MI355X: event record + stream wait
-// pairs cost ~10 us per step, an in-stream gather ~2 us; scripts/comm_overhead_probe.py).
-int rvll_allgather_logl(rvll_handle* h, int64_t B_local)
-{
-    int rc = use_device(h);
-    if (rc) return rc;
-    if (!h->nccl_comm[0]) return fail(RVLL_E_RCCL, "rvll_comm_init has not been called");
-    if (B_local < 1 || B_local > h->cap) return fail(RVLL_E_INVALID, "B_local %lld outside reserved capacity %lld", (long long)B_local, h->cap);
-    const long long total = (long long)B_local * h->nranks;
-    if (total > h->gather_cap) {
-        HIP_TRY(hipStreamSynchronize(h->compute));
-        rc = sync_other_lanes(h);
-        if (rc) return rc;
-        for (int l = 0; l < kMaxLanes; ++l) dev_free(h->d_gather2[l]);
-        h->gather_cap = 0;
-        for (int l = 0; l < h->nlanes; ++l) HIP_TRY(hipMalloc(&h->d_gather2[l], sizeof(double) * (size_t)total));
-        h->gather_cap = total;
-    }
-    const int lane = h->logl_last;            // the lane whose kernel just wrote its log-L
-    RCCL_TRY(g_rccl.AllGather(h->d_logL2[lane], h->d_gather2[lane], (size_t)B_local, kNcclFloat64,
-                              h->nccl_comm[lane], lane_stream(h, lane)));
-    h->gather_last = lane;
-    if (h->nlanes > 1) h->logl_cur = (lane + 1) % h->nlanes;   // the next step runs on the next lane
-    return RVLL_OK;
-}
-
-int rvll_allgather_theta(rvll_handle* h, int64_t B_local)
-{
-    int rc = use_device(h);
-    if (rc) return rc;
-    if (!h->nccl_comm[0]) return fail(RVLL_E_RCCL, "rvll_comm_init has not been called");
-    if (B_local < 1 || B_local > h->cap) return fail(RVLL_E_INVALID, "B_local %lld outside reserved capacity %lld", (long long)B_local, h->cap);
-    const long long total = (long long)B_local * h->nranks;
-    const size_t D = (size_t)std::max(1, h->L.ndim);
-    if (total > h->gather_theta_cap) {
-        HIP_TRY(hipStreamSynchronize(h->compute));
-        dev_free(h->d_gather_theta);
-        h->gather_theta_cap = 0;
-        HIP_TRY(hipMalloc(&h->d_gather_theta, sizeof(double) * D * (size_t)total));
-        h->gather_theta_cap = total;
-    }
-    // theta is written on lane 0's stream (upload or prior kernel); the gather queues behind it there, on
-    // lane 0's communicator — the same stream and communicator lane 0's log-L gathers use, so the two never
-    // run concurrently on one communicator
-    RCCL_TRY(g_rccl.AllGather(h->d_theta, h->d_gather_theta, (size_t)B_local * D, kNcclFloat64,
-                              h->nccl_comm[0], h->compute));
-    return RVLL_OK;
-}
-
-// All-gather of a small host buffer (the sampler's sharded host state: walk end points, call counts): n_local
-// doubles per rank go up, are gathered on the device by RCCL on lane 0's communicator and stream, and nranks *
-// n_local come back, rank-major.  Synchronous.
-int rvll_allgather_host(rvll_handle* h, const double* mine, int64_t n_local, double* all)
-{
-    int rc = use_device(h);
-    if (rc) return rc;
-    if (!h->nccl_comm[0]) return fail(RVLL_E_RCCL, "rvll_comm_init has not been called");
-    if (!mine || !all || n_local < 1) return fail(RVLL_E_INVALID, "bad allgather_host arguments");
-    const size_t total = (size_t)n_local * (size_t)h->nranks;
-    // a grow-only pair of device buffers kept in the handle (freed by rvll_destroy): a sharded sampler calls this once
-    // per iteration, and hipMalloc / hipFree per call synchronise the whole device — every lane of every handle
-    // 
-    if ((long long)total > h->gather_host_cap) {
-        HIP_TRY(hipStreamSynchronize(h->compute));
-        dev_free(h->d_gather_host_in); dev_free(h->d_gather_host_out);
-        h->gather_host_cap = 0;
-        const size_t cap = std::max<size_t>(total, 4096);
-        HIP_TRY(hipMalloc(&h->d_gather_host_in, sizeof(double) * cap));      // (n_local <= total)
-        HIP_TRY(hipMalloc(&h->d_gather_host_out, sizeof(double) * cap));
-        h->gather_host_cap = (long long)cap;
-    }
-    HIP_TRY(hipMemcpyAsync(h->d_gather_host_in, mine, sizeof(double) * (size_t)n_local, hipMemcpyHostToDevice, h->compute));
-    const int r = g_rccl.AllGather(h->d_gather_host_in, h->d_gather_host_out, (size_t)n_local, kNcclFloat64, h->nccl_comm[0], h->compute);
-    if (r != 0) {
-        (void)hipStreamSynchronize(h->compute);
-        return fail(RVLL_E_RCCL, "ncclAllGather failed: %s", g_rccl.GetErrorString(r));
-    }
-    HIP_TRY(hipMemcpyAsync(all, h->d_gather_host_out, sizeof(double) * total, hipMemcpyDeviceToHost, h->compute));
-    HIP_TRY(hipStreamSynchronize(h->compute));
-    return RVLL_OK;
-}
-
-int rvll_download_gathered_theta(rvll_handle* h, int64_t B_total, double* theta_all)
-{
-    int rc = use_device(h);
-    if (rc) return rc;
-    if (!theta_all || B_total < 1 || B_total > h->gather_theta_cap) return fail(RVLL_E_INVALID, "bad gathered theta download");
-    HIP_TRY(hipMemcpyAsync(theta_all, h->d_gather_theta, sizeof(double) * (size_t)B_total * (size_t)h->L.ndim,
-                           hipMemcpyDeviceToHost, h->compute));
-    HIP_TRY(hipStreamSynchronize(h->compute));
-    return RVLL_OK;
-}
-
-int rvll_download_gathered(rvll_handle* h, int64_t B_total, double* logL_all)
-{
-    int rc = use_device(h);
-    if (rc) return rc;
-    if (!logL_all || B_total < 1 || B_total > h->gather_cap) return fail(RVLL_E_INVALID, "bad gathered download");
-    hipStream_t st = lane_stream(h, h->gather_last);
-    HIP_TRY(hipMemcpyAsync(logL_all, h->d_gather2[h->gather_last], sizeof(double) * (size_t)B_total, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    return RVLL_OK;
-}
-
-int rvll_comm_destroy(rvll_handle* h)
-{
-    int rc = use_device(h);
-    if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(h->compute));
-    rc = sync_other_lanes(h);
-    if (rc) return rc;
-    for (int lane = kMaxLanes - 1; lane >= 0; --lane) {
-        if (h->nccl_comm[lane] && g_rccl.lib) RCCL_TRY(g_rccl.CommDestroy(h->nccl_comm[lane]));
-        h->nccl_comm[lane] = nullptr;
-    }
-    h->nranks = 1;
-    h->rank = 0;
-    h->nlanes = 1;
-    h->logl_cur = 0;
-    return RVLL_OK;
-}
-
 }  // extern "C"
+
+// ---- the helpers the other host units call (rvll_host.h) ----
+namespace rvll {
+namespace host {
+int use_device(rvll_handle* h) { return ::use_device(h); }
+int sync_other_lanes(rvll_handle* h) { return ::sync_other_lanes(h); }
+int build_args(rvll_handle* h, const double* d_theta, double* d_logL, int32_t* d_flags, long long B, rvll::LoglikeArgs* out, int* cu_grid)
+{
+    return ::build_args(h, d_theta, d_logL, d_flags, B, out, cu_grid);
+}
+void make_fused(const rvll_handle* h, const double* d_cube, double* d_theta_out, rvll::LoglikeArgs* a) { ::make_fused(h, d_cube, d_theta_out, a); }
+int download_rows(rvll_handle* h, void* dst, const void* src_dev, size_t bytes) { return ::download_rows(h, dst, src_dev, bytes); }
+}  // namespace host
+}  // namespace rvll
