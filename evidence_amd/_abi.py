@@ -127,6 +127,7 @@ PROTOTYPES = {
     "rvll_set_walk_speculation": (C.c_int, [Handle, C.c_int32]),
     "rvll_slice_walk_evaluated": (C.c_int, [Handle, C.POINTER(C.c_int64)]),
     "rvll_slice_walk_phases": (C.c_int, [Handle, C.POINTER(C.c_uint64)]),
+    "rvll_slice_walk_rounds": (C.c_int, [Handle, C.POINTER(C.c_int32)]),
     "rvll_comm_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
     "rvll_comm_init": (C.c_int, [Handle, C.POINTER(C.c_ubyte), C.c_int32, C.c_int32]),
     "rvll_comm_add_lanes": (C.c_int, [Handle, C.c_int32, _ip]),

@@ -504,6 +504,9 @@ int rvll_destroy(rvll_handle* h)
     if (h->pin_defer) (void)hipHostFree(h->pin_defer);
     stream_free(h);
     dev_free(h->d_walk_steps); dev_free(h->d_walk_wid); dev_free(h->d_walk_start); dev_free(h->d_walk_cost); dev_free(h->d_walk_order);
+    dev_free(h->d_rounds); dev_free(h->d_walk_dirs);
+    if (h->pin_rounds) (void)hipHostFree(h->pin_rounds);
+    if (h->ev_rounds) (void)hipEventDestroy(h->ev_rounds);
     for (auto& e : h->marks) if (e) (void)hipEventDestroy(e);
     if (h->srv_stream) (void)hipStreamDestroy(h->srv_stream);
     if (h->srv) (void)hipHostFree(h->srv);
@@ -602,6 +605,9 @@ int rvll_set_priors(rvll_handle* h, const rvll_prior* priors, int32_t ndim)
     HIP_TRY(hipMalloc(&h->d_priors, sizeof(rvll_prior) * (size_t)std::max(1, ndim)));
     if (ndim) HIP_TRY(hipMemcpy(h->d_priors, dev.data(), sizeof(rvll_prior) * (size_t)ndim, hipMemcpyHostToDevice));
     std::vector<int32_t> heavy, light;
+    h->priors_rowwise = false;
+    for (int d = 0; d < ndim; ++d)
+        if (priors[d].kind == RVLL_PRIOR_SORTED_UNIFORM || priors[d].kind == RVLL_PRIOR_SORTED_LOGUNIFORM) h->priors_rowwise = true;
     for (int d = 0; d < ndim; ++d)
         (priors[d].kind == RVLL_PRIOR_BETA || priors[d].kind == RVLL_PRIOR_GAMMA ? heavy : light).push_back(d);
     // the light kinds grouped by what their quantile costs (pow / ndtri / exp + log / table search / a division / nothing),

@@ -89,6 +89,7 @@ struct rvll_handle {
     std::vector<double*> d_tables;
     std::vector<double> table_err;              // measured quintic-interpolant error per parameter (NaN: no table)
     std::vector<int> table_direct;              // per parameter: evaluated by verified interpolation alone
+    bool priors_rowwise = false;                // some prior reads other coordinates of its row (the sorted kinds)
     bool all_direct = true;                     // every Beta / Gamma prior has a verified table: the slim prior stage applies
     double slim_umax = 0.;                      // |logit q| range the slim stage takes (rvll_set_slim_table_range; default: the table's)
     int* pin_defer = nullptr;                   // mapped pinned word the slim stage sets when it defers an element
@@ -140,6 +141,17 @@ struct rvll_handle {
     int32_t *d_walk_steps = nullptr, *d_walk_wid = nullptr, *d_walk_start = nullptr;   // [walk_cap] each
     int32_t *d_walk_cost = nullptr, *d_walk_order = nullptr;                            // [walk_cap] each (two-part walks)
     int walk_spec = 4;                          // candidates a walker may evaluate ahead per iteration (rvll_set_walk_speculation)
+    // the walk as rounds of launches (rvll_rounds.hip; walk_rounds in rvll_walk_host.hip): one arena with every group's walker
+    // state, candidate slots and counters; a progress word per group in mapped pinned memory
+    int walk_spec_rounds = 8;                   // ... and per round of the rounds form, while a round is below the latency floor
+    void* d_rounds = nullptr;
+    double* d_walk_dirs = nullptr;              // [K, nsteps, D] the directions of all moves of the walk in progress
+    size_t walk_dirs_cap = 0;                   // in doubles
+    size_t rounds_bytes = 0;
+    unsigned long long* pin_rounds = nullptr;   // [kMaxLanes]
+    unsigned long long* pin_rounds_dev = nullptr;
+    hipEvent_t ev_rounds = nullptr;             // orders the groups' streams behind lane 0
+    int walk_rounds_used = 0;                   // rounds the last walk took (0: it ran in one of the single-kernel forms)
     long long walk_evaluated = 0;               // tile slots the last rvll_slice_walk evaluated (>= its ncalls)
     unsigned long long walk_phase[6] = {};      // diagnostic build (make walktrace): 100 MHz ticks per phase, summed over workgroups; workgroups
 

@@ -126,6 +126,92 @@ size_t walk_rows_lds_bytes(const LoglikeArgs& a, int rows_per_wg);
 // forms, a.CH >= a.PB * a.Ne: the tile draws wave rounds from its ticket counter); the wide forms exist for the slim stage only
 hipError_t launch_slice_walk_rows(const LoglikeArgs& a, const WalkArgs& w, bool fat, int nblocks, int nt, hipStream_t stream);
 
+// ---- the walk as ROUNDS of launches over walker state resident in HBM (rvll_rounds.h, rvll_kernels.hip) -----------------------------------
+// The kernels above keep a walker's state in its workgroup's LDS for the whole walk, and a workgroup's iteration — propose,
+// prior stage, decode, items, reduce, accept, bookkeeping: a dozen barrier intervals — evaluates the eight to ten candidates
+// of ITS walkers: 2600 vector instructions a candidate at 75-79 % VALU-busy against the batch kernel's 1990 at 99 %
+// (profiles/r03_walk_forms.txt), whatever the structure inside the workgroup.  Here a round is two launches over a GROUP of
+// walkers: rounds_step_kernel consumes the previous round's results (accept / shrink, in the order the walker would have met
+// them), draws directions for the walkers that start a move and writes this round's candidates — one per listed walker, more
+// ahead while the round is below the chip's latency floor — into ONE compact array, prior transform included; then the batch
+// log-L kernel itself (the theta -> log-L tile, rvll_tile.h) evaluates that array, every workgroup an equal share of however many
+// candidates there are (the count stays on the device).  No host synchronisation between rounds; with two or more groups one
+// group's step rides in the launch of another group's tiles (rounds_kernel).  The random-number counters name the walker,
+// so end points, theta, log-L and the call count are those of slice_walk_kernel bit for bit (tests/test_gpu_walk.py).
+constexpr int kRoundsRing = 16;        // per-round counters (slots handed out, walkers listed) live in a ring of this many rounds
+struct RoundsArgs {
+    double* u;                 // [K, D] the group's walkers: in start, out end positions (unit cube)
+    double* theta;             // [K, D] theta of the accepted positions
+    double* logl;              // [K]
+    double* dir;               // [K, D] unit direction of the move in progress
+    double* dirnext;           // [K, D] ... of the move after it (copied from dirs when a move starts: the step that needs it
+                               //         finds it at a fixed address)
+    const double* dirs;        // [K, nsteps, D] the directions of all moves of the group's walkers (rounds_dirs)
+    double* tmin;              // [K] bracket of the move in progress
+    double* tmax;              // [K]
+    int32_t* step;             // [K] moves completed (out: steps_done — < nsteps: stopped at a candidate the slim stage deferred)
+    int32_t* ws;               // [K, 4] state (0 starts a move, 1 in a move, 3 deferred, 4 finished), round, first slot, slots
+    long long K;
+    unsigned long long wid0;   // random-number counter index of the group's first walker (walker_base + its row)
+    double* theta_c[2];        // [C, D] the candidates of even / odd rounds, compacted and prior-transformed: the tiles' batch
+                               //         (theta -> log-L); a step still reads the previous round's rows — theta of what it accepts
+    int32_t* owner;            // [C] per slot: walker * spec_max + its index among the walker's slots (where the tiles put the result)
+    double* wt;                // [K, spec_max] per walker: its candidates' positions along its direction
+    int32_t* wdef;             // [K, spec_max] ... 1: a coordinate's quantile is beyond the verified tables (the walker is deferred)
+    const double* wres_logl;   // [K, spec_max] per walker: what the tiles made of them
+    const int32_t* wres_flags; // [K, spec_max]
+    const rvll_prior* priors;  // [D] the prior stage of the step (as LoglikeArgs: light kinds grouped, iterative kinds by table)
+    const int32_t* light_dims; // [D - n_heavy]
+    const int32_t* heavy_dims; // [n_heavy]
+    int n_heavy;
+    int inplace;               // 1: no prior reads other coordinates of its row (no sorted kind): transformed in place in LDS
+    double slim_umax;
+    int C;                     // slots (>= K)
+    int c_free;                // slots a round holds at the log-L kernel's latency floor: walkers get candidates AHEAD up to here
+    const int32_t* wrapped;    // [D]
+    int D, W;                  // W: walkers per workgroup of the step (<= 64: one lane of a wave each)
+    int nsteps, max_rounds, spec_max;
+    unsigned long long seed;
+    double lstar;
+    int32_t* ring;             // [kRoundsRing, 2] per round (8-byte aligned pairs): slots handed out = the tiles' batch, walkers listed
+    long long* calls_part;     // [workgroups] likelihood calls consumed, summed by the host (a workgroup owns its entry: no atomics)
+    unsigned long long* slots_part;   // [workgroups] slots evaluated (>= calls: candidates ahead that went unused)
+    unsigned long long* stamps;       // diagnostic (RVLL_ROUNDS_STAMPS) or null: per round and workgroup 4 x s_memrealtime (100 MHz)
+    int stamp_rounds;
+};
+// the directions of every move of every walker, in front of the rounds
+struct RoundsDirs {
+    double* dirs;              // [K, nsteps, D]
+    const double* chol;        // [D, D] whitening factor
+    long long K;
+    unsigned long long wid0;   // random-number counter index of the first walker
+    unsigned long long seed;
+    int D, nsteps;
+};
+hipError_t launch_rounds_dirs(const RoundsDirs& g, int max_blocks, hipStream_t stream);
+// what the tiles of a round need beside their LoglikeArgs (a.theta = the group's theta_c)
+struct RoundsTiles {
+    const int32_t* ring_entry;        // [2] slots to evaluate, walkers listed (the step of this round filled it)
+    unsigned long long* progress;     // mapped pinned host memory or null: (round + 1) << 32 | walkers listed, when the tiles start
+    const int32_t* owner;             // [C]
+    double* wres_logl;                // [K, spec_max]
+    int32_t* wres_flags;              // [K, spec_max]
+};
+int rounds_walkers_per_block(int D, int spec_max, size_t lds_budget);
+size_t rounds_step_lds_bytes(int W, int D, int spec_max);
+int rounds_blocks_per_cu(size_t lds_bytes);
+// One launch (rvll_kernels.hip, rounds_kernel), `lds` bytes of dynamic LDS per workgroup: round r_step of the group *step (or
+// null) next to the log-L tiles of round r_ll of ANOTHER group — *ll with *out (or null) over `tiles` 256-thread workgroups of
+// at most a.PB points, equal shares of the count in out->ring_entry[0].  The two parts must not depend on each other.
+hipError_t launch_rounds(const RoundsArgs* step, int r_step, const LoglikeArgs* ll, const RoundsTiles* out, int tiles, int r_ll,
+                         size_t lds, hipStream_t stream);
+
+// the two parts as launches of their own (a stream per group)
+hipError_t launch_rounds_step(const RoundsArgs& g, int round, hipStream_t stream);
+hipError_t launch_rounds_tiles(const LoglikeArgs& a, const RoundsTiles& out, int tiles, int round, hipStream_t stream);
+// the tiles of a round alone, in the CU-wide form: `tiles` 1024-thread workgroups of at most a.PB points (a.CH >= a.PB * a.Ne)
+hipError_t launch_rounds_cu(const LoglikeArgs& a, const RoundsTiles& out, int tiles, int round, hipStream_t stream);
+
 // ---- device-resident live set (rvll_live.hip): row gather / scatter by index; mean and covariance of a subset of rows
 hipError_t launch_gather_rows(const double* src, const int32_t* idx, long long n, int width, double* dst, hipStream_t st);
 hipError_t launch_scatter_rows(const double* src, const int32_t* idx, long long n, int width, double* dst, hipStream_t st);

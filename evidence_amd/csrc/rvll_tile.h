@@ -244,6 +244,17 @@ __device__ __forceinline__ double prior_heavy_slim(const rvll_prior& pr, double 
     return NAN;
 }
 
+// One standard normal from two counter-based uniforms (Box-Muller, the cosine branch): u1 in [0, 1) so 1 - u1 is in
+// (0, 1] — log_pos (rvll_math.h: a third of the library log's instructions) takes it.  Every form of the proposal walk
+// (rvll_walk.hip, rvll_rounds.hip) draws its directions through this one function, so every form sees the same numbers.
+__device__ __forceinline__ double walk_normal(unsigned long long seed, unsigned long long ctr)
+{
+    const double u1 = uniform01(seed, ctr), u2 = uniform01(seed, ctr + 1);
+    double sn, cs;
+    sincos_f64(kTwoPi * u2, sn, cs);
+    return sqrt(-2. * log_pos(1. - u1)) * cs;
+}
+
 // Per-block LDS views handed to eval_item (plain pointers; the kernel arguments
 // themselves are passed by reference so they stay in the scalar kernarg segment).
 struct ItemCtx {

@@ -17,17 +17,6 @@ namespace rvll {
 
 namespace {
 
-// One standard normal from two counter-based uniforms (Box-Muller, the cosine branch): u1 in [0, 1) so 1 - u1 is in
-// (0, 1] — log_pos (rvll_math.h: a third of the library log's instructions) takes it.  Every walk kernel draws its
-// directions through this one function, so every form of the walk sees the same numbers.
-__device__ __forceinline__ double walk_normal(unsigned long long seed, unsigned long long ctr)
-{
-    const double u1 = uniform01(seed, ctr), u2 = uniform01(seed, ctr + 1);
-    double sn, cs;
-    sincos_f64(kTwoPi * u2, sn, cs);
-    return sqrt(-2. * log_pos(1. - u1)) * cs;
-}
-
 // Device-resident slice-sampling walk (rvll_kernels.h, WalkArgs; the scheme of evidence_amd/nested.py
 // run_nested_slice, which follows the reference's UltraNest wrapper: region slice sampling, nsteps moves per new
 // point, circular omega / ml0 — evidence/ultranest/__init__.py:159-175).  Everything a move needs stays on the

@@ -1,6 +1,8 @@
 // rvll_walk_host.hip — host side of the sampler's proposal step: the device-resident slice-sampling walk
 // in its forms (rvll_slice_walk) and the live set of nested sampling kept in HBM (rvll_live_*).  Entry points of include/rvll.h;
 // the kernels are in rvll_walk.hip, rvll_rounds.hip and rvll_live.hip.
+#include <chrono>
+#include <thread>
 #include "rvll_host.h"
 
 using rvll::report_error;
@@ -38,6 +40,318 @@ int walk_reserve(rvll_handle* h, int64_t K)
         }
         h->walk_cap = (long long)cap;
     }
+    return RVLL_OK;
+}
+
+// ---- the walk as rounds of launches (rvll_rounds.hip) ----------------------------------------------------------------
+// Which walks take it: RVLL_WALK_ROUNDS = 0 never / 1 whenever the slim prior stage applies; by default every walk the slim
+// stage applies to, unless one of the switches that select a single-kernel form is set (RVLL_WALK_QUEUE / _PARTS / _ROWS /
+// _FAT: the tests and the measurements of those forms).
+bool rounds_wanted()
+{
+    if (const char* e = getenv("RVLL_WALK_ROUNDS")) return atoi(e) != 0;
+    return !getenv("RVLL_WALK_QUEUE") && !getenv("RVLL_WALK_PARTS") && !getenv("RVLL_WALK_ROWS") && !getenv("RVLL_WALK_FAT");
+}
+
+// The K rows of d_walk_u / d_walk_theta / d_walk_logl (chol, wrapped uploaded) walked in rounds: G groups of rows; a group's
+// round = its step, then the batch log-L tiles over its candidates — and every launch carries the tiles of one group next to
+// the step of another (rvll_kernels.hip, rounds_kernel), all in lane 0's stream.  The host only keeps the queue a few rounds
+// deep: the tiles publish (round, walkers listed) to a word per group in mapped pinned memory; a group is done when a round
+// listed nobody (what is already queued behind it finds nothing to do).  Leaves the end points in the walk buffers, moves
+// completed in d_walk_steps (a walker the slim prior stage deferred: < nsteps), and synchronises the stream.
+// *calls: likelihood calls consumed; *slots: candidates evaluated.
+// Returns RVLL_E_UNSUPPORTED without having launched anything if the step's state does not fit (huge D).
+int walk_rounds(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t max_rounds, uint64_t seed, int64_t walker_base,
+                long long* calls, long long* slots)
+{
+    using namespace std::chrono;
+    const int D = h->L.ndim;
+    int spec = h->walk_spec_rounds;
+    if (const char* e = getenv("RVLL_WALK_SPEC")) spec = atoi(e);       // measurement switch (1: no candidates ahead)
+    spec = std::max(1, std::min(spec, rvll::kMaxPointsPerBlock));
+    int G = 2;
+    if (const char* e = getenv("RVLL_ROUNDS_GROUPS")) G = atoi(e);
+    G = (int)std::max<long long>(1, std::min<long long>(std::min(G, kMaxLanes), K));
+    // slots a round holds at the log-L kernel's latency floor — about two wave rounds per wave of the chip, shared by the
+    // groups — and with it the capacity of a group's candidate array
+    long long c_free = std::max<long long>(256, (long long)h->n_cu * 2048 / std::max(1, h->Ne) / G);
+    if (const char* e = getenv("RVLL_ROUNDS_FREE")) c_free = std::max(1, atoi(e));
+    // How the rounds are issued (RVLL_ROUNDS_MODE / RVLL_ROUNDS_FORM, measurement switches):
+    //   fused    one stream; every launch = one group's tiles (256-thread form) + another group's step (rounds_kernel)
+    //   streams  a stream per group; a group's round = a step launch, then a tiles launch (256-thread form or CU-wide)
+    const char* menv = getenv("RVLL_ROUNDS_MODE");
+    const char* fenv = getenv("RVLL_ROUNDS_FORM");
+    const bool fused = menv ? !strcmp(menv, "fused") : false;
+    const bool cu_form = !fused && (fenv ? !strcmp(fenv, "cu") : true);
+    rvll::LoglikeArgs a;
+    long long per = (K + G - 1) / G;
+    int rc = build_args(h, nullptr, nullptr, nullptr, std::max(per, c_free), &a);
+    if (rc) return rc;
+    // the step's walkers per workgroup: within what leaves four workgroups a compute unit when it shares its launches (and with
+    // them the size of the dynamic LDS) with the tiles, up to a wave's lanes otherwise
+    const size_t lds_budget = fused ? std::max<size_t>(rvll::loglike_lds_bytes(a), 36 * 1024) : (size_t)60 * 1024;
+    int W = rvll::rounds_walkers_per_block(D, spec, lds_budget);
+    if (W < 1) return RVLL_E_UNSUPPORTED;
+    if (const char* e = getenv("RVLL_ROUNDS_W")) W = std::max(1, std::min(W, atoi(e)));      // measurement switch
+    per = (per + W - 1) / W * W;
+    G = (int)((K + per - 1) / per);
+    const long long C = std::max(per, c_free), nblk = per / W;
+    c_free = std::min(c_free, C);
+    if (C >= (1LL << 30) || per * spec >= (1LL << 31)) return RVLL_E_UNSUPPORTED;
+    const size_t step_lds = rvll::rounds_step_lds_bytes(W, D, spec);
+    auto window = [&](int pb) { return (std::min(h->chunk_items, std::max(rvll::kThreads, pb * h->Ne)) + 1) & ~1; };
+    if (cu_form) {
+        // one CU-wide tile per compute unit: every contribution of the tile resident in LDS
+        int pb = (int)std::min<long long>(rvll::kCuMaxPoints, (C + h->n_cu - 1) / h->n_cu);
+        rvll::LoglikeArgs b = a;
+        auto fits = [&](int q) { b.PB = q; b.CH = (q * h->Ne + 1) & ~1; return rvll::loglike_lds_bytes(b) <= rvll::kCuLdsBudget; };
+        while (pb > 1 && !fits(pb)) --pb;
+        if (!fits(pb)) return RVLL_E_UNSUPPORTED;
+        a = b;
+    } else {
+        // 256-thread tiles sized to the wave slots the chip has left beside one group's step workgroups (but never smaller
+        // than the cost model's choice): a tile that waits for a step's slot ends its launch a step's latency late
+        const size_t lds0 = fused ? std::max(rvll::loglike_lds_bytes(a), step_lds) : rvll::loglike_lds_bytes(a);
+        const int occ = rvll::rounds_blocks_per_cu(lds0);
+        const long long room = (long long)std::max(1, occ) * h->n_cu - (G > 1 ? nblk : 0);
+        const long long want = room > 0 ? (C + room - 1) / room : a.PB;
+        if (want > a.PB && want <= rvll::kMaxPointsPerBlock) {
+            rvll::LoglikeArgs b = a;
+            b.PB = (int)want; b.CH = window((int)want);
+            if (rvll::loglike_lds_bytes(b) <= lds_budget) a = b;
+        }
+        if (const char* e = getenv("RVLL_ROUNDS_PB")) {          // measurement switch: points per tile
+            const int pb = std::max(1, std::min(atoi(e), rvll::kMaxPointsPerBlock));
+            rvll::LoglikeArgs b = a;
+            b.PB = pb; b.CH = window(pb);
+            if (rvll::loglike_lds_bytes(b) <= 60 * 1024) a = b;
+        }
+    }
+    const size_t lds = fused ? std::max(rvll::loglike_lds_bytes(a), step_lds) : rvll::loglike_lds_bytes(a);
+    const int tiles = (int)((C + a.PB - 1) / a.PB);
+    if (getenv("RVLL_WALK_GEOM_DUMP"))
+        fprintf(stderr, "[rounds] K=%lld G=%d %s %s per=%lld C=%lld c_free=%lld W=%d step blocks=%lld PB=%d tiles=%d lds=%zu spec=%d\n", (long long)K, G,
+                fused ? "fused" : "streams", cu_form ? "cu" : "tile", per, C, c_free, W, nblk, a.PB, tiles, lds, spec);
+    // arena: per group  doubles | 64-bit words | walker words (int4) | ints
+    const size_t n_dbl = 2 * (size_t)per * D + 2 * (size_t)per + 2 * (size_t)C * D + 2 * (size_t)per * spec + (size_t)C;
+    const size_t n_ll = 2 * (size_t)nblk + rvll::kRoundsRing;
+    const size_t n_int = 4 * (size_t)per + 2 * (size_t)per * spec + 2 * (size_t)C;
+    auto up16 = [](size_t b) { return (b + 15) & ~(size_t)15; };
+    const size_t g_bytes = up16(8 * n_dbl) + up16(8 * n_ll) + up16(4 * n_int);
+    hipStream_t st = h->compute;
+    if ((size_t)G * g_bytes > h->rounds_bytes) {
+        HIP_TRY(hipStreamSynchronize(st));
+        dev_free(h->d_rounds);
+        h->rounds_bytes = 0;
+        HIP_TRY(hipMalloc(&h->d_rounds, (size_t)G * g_bytes));
+        h->rounds_bytes = (size_t)G * g_bytes;
+    }
+    if (!h->pin_rounds) {
+        void *p = nullptr, *pd = nullptr;
+        HIP_TRY(hipHostMalloc(&p, sizeof(unsigned long long) * kMaxLanes, hipHostMallocMapped | hipHostMallocCoherent));
+        HIP_TRY(hipHostGetDevicePointer(&pd, p, 0));
+        h->pin_rounds = static_cast<unsigned long long*>(p);
+        h->pin_rounds_dev = static_cast<unsigned long long*>(pd);
+    }
+    // the directions of every move of every walker, ahead of the rounds (rvll_rounds.h, rounds_dirs)
+    {
+        const size_t need = (size_t)K * (size_t)nsteps * (size_t)D;
+        if (need > h->walk_dirs_cap) {
+            HIP_TRY(hipStreamSynchronize(h->compute));
+            dev_free(h->d_walk_dirs);
+            h->walk_dirs_cap = 0;
+            HIP_TRY(hipMalloc(&h->d_walk_dirs, sizeof(double) * need));
+            h->walk_dirs_cap = need;
+        }
+        const rvll::RoundsDirs dg{h->d_walk_dirs, h->d_walk_chol, (long long)K, (unsigned long long)walker_base, (unsigned long long)seed, D, nsteps};
+        HIP_TRY(rvll::launch_rounds_dirs(dg, 16 * h->n_cu, h->compute));
+    }
+    std::vector<rvll::RoundsArgs> ga((size_t)G);
+    std::vector<rvll::LoglikeArgs> la((size_t)G, a);
+    std::vector<rvll::RoundsTiles> ta((size_t)G);
+    for (int g = 0; g < G; ++g) {
+        char* base = static_cast<char*>(h->d_rounds) + (size_t)g * g_bytes;
+        double* d = reinterpret_cast<double*>(base);
+        long long* ll = reinterpret_cast<long long*>(base + up16(8 * n_dbl));
+        int32_t* in = reinterpret_cast<int32_t*>(base + up16(8 * n_dbl) + up16(8 * n_ll));
+        const long long row0 = (long long)g * per, Kg = std::min<long long>(per, K - row0);
+        rvll::RoundsArgs& r = ga[(size_t)g];
+        r.u = h->d_walk_u + (size_t)row0 * D;  r.theta = h->d_walk_theta + (size_t)row0 * D;  r.logl = h->d_walk_logl + row0;
+        r.step = h->d_walk_steps + row0;
+        r.dir = d;                       d += (size_t)per * D;
+        r.dirnext = d;                   d += (size_t)per * D;
+        r.dirs = h->d_walk_dirs + (size_t)row0 * nsteps * D;
+        r.tmin = d;                      d += per;
+        r.tmax = d;                      d += per;
+        r.theta_c[0] = d;                d += (size_t)C * D;
+        r.theta_c[1] = d;                d += (size_t)C * D;
+        r.wt = d;                        d += (size_t)per * spec;
+        double* wres_logl = d;           d += (size_t)per * spec;
+        double* res_logl = d;
+        r.wres_logl = wres_logl;
+        r.calls_part = ll;  r.slots_part = reinterpret_cast<unsigned long long*>(ll + nblk);
+        r.ring = reinterpret_cast<int32_t*>(ll + 2 * nblk);            // (8-byte aligned pairs: one 64-bit atomic a workgroup)
+        r.ws = in;                       in += 4 * per;
+        int32_t* wres_flags = in;        in += per * spec;
+        r.wdef = in;                     in += per * spec;
+        int32_t* res_flags = in;         in += C;
+        r.owner = in;
+        r.wres_flags = wres_flags;
+        r.priors = h->d_priors;  r.heavy_dims = h->d_heavy;  r.n_heavy = h->n_heavy;  r.light_dims = h->d_heavy + h->n_heavy;
+        r.inplace = h->priors_rowwise ? 0 : 1;  r.slim_umax = h->slim_umax;
+        r.K = Kg;  r.wid0 = (unsigned long long)(walker_base + row0);
+        r.C = (int)C;  r.c_free = (int)c_free;
+        r.wrapped = h->d_walk_wrapped;
+        r.D = D;  r.W = W;  r.nsteps = nsteps;  r.max_rounds = max_rounds;  r.spec_max = spec;
+        r.seed = seed;  r.lstar = lstar;
+        rvll::LoglikeArgs& l = la[(size_t)g];
+        l.theta = r.theta_c[0];  l.logL = res_logl;  l.flags = res_flags;  l.B = C;      // the tiles: theta -> log-L
+        ta[(size_t)g] = rvll::RoundsTiles{nullptr, h->pin_rounds_dev + g, r.owner, wres_logl, wres_flags};
+        r.stamps = nullptr;  r.stamp_rounds = 0;
+        HIP_TRY(hipMemsetAsync(ll, 0, up16(8 * n_ll), st));          // the partial sums and the ring
+        h->pin_rounds[g] = 0;
+    }
+    // diagnostic (RVLL_ROUNDS_STAMPS=n): time stamps of group 0's step workgroups over its first n rounds, dumped to stderr
+    unsigned long long* d_stamps = nullptr;
+    int stamp_rounds = 0;
+    if (const char* e = getenv("RVLL_ROUNDS_STAMPS")) {
+        stamp_rounds = std::max(0, std::min(atoi(e), 4096));
+        if (stamp_rounds) {
+            const size_t nb = sizeof(unsigned long long) * 8 * (size_t)stamp_rounds * (size_t)nblk;
+            HIP_TRY(hipMalloc(&d_stamps, nb));
+            HIP_TRY(hipMemsetAsync(d_stamps, 0, nb, h->compute));
+            ga[0].stamps = d_stamps;  ga[0].stamp_rounds = stamp_rounds;
+        }
+    }
+    const long long r_max = (long long)nsteps * max_rounds + 2;       // every round consumes a candidate of every listed walker
+    int depth = 4;                                                      // rounds queued beyond the last one seen starting
+    if (const char* e = getenv("RVLL_ROUNDS_DEPTH")) depth = std::max(1, atoi(e));
+    // per group: rounds whose step / whose tiles have been launched (tiles <= step <= tiles + 1: the next thing a group needs
+    // is its step when they are equal, its tiles otherwise)
+    std::vector<long long> n_step((size_t)G, 0), n_tile((size_t)G, 0);
+    std::vector<char> done((size_t)G, 0);
+    int ndone = 0, status = RVLL_OK, turn = 0;
+    auto last_progress = steady_clock::now();
+    const auto t_walk0 = steady_clock::now();
+    long long launch_ns = 0, n_launch = 0;
+    unsigned long long seen_sum = 0;
+    if (!fused && G > 1) {
+        // the groups' streams start behind what lane 0 holds (uploads, the live step's gathers, the zeroing above)
+        if (!h->ev_rounds) HIP_TRY(hipEventCreateWithFlags(&h->ev_rounds, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(h->ev_rounds, h->compute));
+        for (int g = 1; g < G; ++g) HIP_TRY(hipStreamWaitEvent(h->lanes[g], h->ev_rounds, 0));
+    }
+    auto tiles_of = [&](int g, int r, hipStream_t s) -> hipError_t {
+        ta[(size_t)g].ring_entry = ga[(size_t)g].ring + 2 * (r % rvll::kRoundsRing);
+        la[(size_t)g].theta = ga[(size_t)g].theta_c[r & 1];
+        return cu_form ? rvll::launch_rounds_cu(la[(size_t)g], ta[(size_t)g], tiles, r, s)
+                       : rvll::launch_rounds_tiles(la[(size_t)g], ta[(size_t)g], tiles, r, s);
+    };
+    while (ndone < G && status == RVLL_OK) {
+        unsigned long long sum = 0;
+        bool any = false;
+        if (fused) {
+            // the next launch: the tiles of the first group (from `turn` on) that has a step waiting to be evaluated, next to
+            // the step of the first OTHER group that needs one.  A pair is launched as a pair: while one of the two is at its
+            // queue depth nothing goes out — launching the other alone would put every later launch out of step, one part each
+            // (the groups become eligible one at a time as their rounds start: measured, 7.4e7 calls/s against 1.4e8).
+            int g_tile = -1, g_step = -1;
+            bool blocked = false;
+            for (int k = 0; k < G; ++k) {
+                const int g = (turn + k) % G;
+                if (done[(size_t)g]) continue;
+                const unsigned long long p = __atomic_load_n(&h->pin_rounds[g], __ATOMIC_ACQUIRE);
+                const long long pub = (long long)(p >> 32);          // rounds whose tiles have started
+                sum += p;
+                if (pub > 0 && (unsigned)p == 0u) { done[(size_t)g] = 1; ++ndone; continue; }
+                const bool full = n_tile[(size_t)g] - pub >= depth;
+                if (n_step[(size_t)g] > n_tile[(size_t)g]) { if (g_tile < 0) { g_tile = g; blocked |= full; } }
+                else if (g_step < 0) { g_step = g; blocked |= full; }
+            }
+            if (blocked) g_tile = g_step = -1;
+            if (g_step >= 0 && n_step[(size_t)g_step] >= r_max) {
+                status = report_error(RVLL_E_HIP, "rounds walk: group %d did not finish in %lld rounds", g_step, r_max);
+                break;
+            }
+            if (g_tile >= 0 || g_step >= 0) {
+                const int rs = g_step >= 0 ? (int)n_step[(size_t)g_step] : 0, rt = g_tile >= 0 ? (int)n_tile[(size_t)g_tile] : 0;
+                if (g_tile >= 0) {
+                    ta[(size_t)g_tile].ring_entry = ga[(size_t)g_tile].ring + 2 * (rt % rvll::kRoundsRing);
+                    la[(size_t)g_tile].theta = ga[(size_t)g_tile].theta_c[rt & 1];
+                }
+                const hipError_t e = rvll::launch_rounds(g_step >= 0 ? &ga[(size_t)g_step] : nullptr, rs, g_tile >= 0 ? &la[(size_t)g_tile] : nullptr,
+                                                         g_tile >= 0 ? &ta[(size_t)g_tile] : nullptr, tiles, rt, lds, h->compute);
+                if (e != hipSuccess) { status = report_error(RVLL_E_HIP, "rounds walk launch failed: %s", hipGetErrorString(e)); break; }
+                if (g_step >= 0) n_step[(size_t)g_step] += 1;
+                if (g_tile >= 0) n_tile[(size_t)g_tile] += 1;
+                turn = (turn + 1) % G;
+                any = true;
+            }
+        } else {
+            for (int g = 0; g < G && status == RVLL_OK; ++g) {
+                if (done[(size_t)g]) continue;
+                const unsigned long long p = __atomic_load_n(&h->pin_rounds[g], __ATOMIC_ACQUIRE);
+                const long long pub = (long long)(p >> 32);
+                sum += p;
+                if (pub > 0 && (unsigned)p == 0u) { done[(size_t)g] = 1; ++ndone; continue; }
+                if (n_tile[(size_t)g] - pub >= depth) continue;
+                if (n_tile[(size_t)g] >= r_max) { status = report_error(RVLL_E_HIP, "rounds walk: group %d did not finish in %lld rounds", g, r_max); break; }
+                const int r = (int)n_tile[(size_t)g];
+                const auto tl0 = steady_clock::now();
+                hipError_t e = rvll::launch_rounds_step(ga[(size_t)g], r, h->lanes[g]);
+                if (e == hipSuccess) e = tiles_of(g, r, h->lanes[g]);
+                launch_ns += duration_cast<nanoseconds>(steady_clock::now() - tl0).count();  n_launch += 2;
+                if (e != hipSuccess) { status = report_error(RVLL_E_HIP, "rounds walk launch failed: %s", hipGetErrorString(e)); break; }
+                n_step[(size_t)g] += 1;
+                n_tile[(size_t)g] += 1;
+                any = true;
+            }
+        }
+        if (any || sum != seen_sum) { last_progress = steady_clock::now(); seen_sum = sum; continue; }
+        if (ndone < G && steady_clock::now() - last_progress > seconds(20)) {
+            status = report_error(RVLL_E_HIP, "rounds walk made no progress for 20 s");
+            break;
+        }
+        std::this_thread::yield();
+    }
+    for (int g = 0; g < (fused ? 1 : G); ++g) {
+        const hipError_t e = hipStreamSynchronize(h->lanes[g]);
+        if (e != hipSuccess && status == RVLL_OK) status = report_error(RVLL_E_HIP, "rounds walk: %s", hipGetErrorString(e));
+    }
+    if (getenv("RVLL_WALK_GEOM_DUMP"))
+        fprintf(stderr, "[rounds host] %lld launches, %.2f us each inside the launch calls, walk %.2f ms\n", n_launch, n_launch ? launch_ns / 1e3 / n_launch : 0.,
+                duration_cast<nanoseconds>(steady_clock::now() - t_walk0).count() / 1e6);
+    if (d_stamps) {
+        std::vector<unsigned long long> sv((size_t)8 * stamp_rounds * nblk);
+        (void)hipMemcpy(sv.data(), d_stamps, sizeof(unsigned long long) * sv.size(), hipMemcpyDeviceToHost);
+        (void)hipFree(d_stamps);
+        const long long nb0 = (ga[0].K + W - 1) / W;
+        for (int r = 0; r < stamp_rounds && r < n_tile[0]; ++r) {
+            unsigned long long t0 = ~0ull, t_last_start = 0, t_end = 0, n = 0;
+            double seg[7] = {};
+            for (long long b = 0; b < nb0; ++b) {
+                const unsigned long long* q = &sv[8 * ((size_t)r * nb0 + b)];
+                if (!q[7]) continue;
+                t0 = std::min(t0, q[0]); t_last_start = std::max(t_last_start, q[0]); t_end = std::max(t_end, q[7]);
+                for (int k = 0; k < 7; ++k) seg[k] += (q[k + 1] >= q[k] && q[k + 1]) ? (double)(q[k + 1] - q[k]) / 100. : 0.;
+                ++n;
+            }
+            if (n) fprintf(stderr, "[step stamps] round %d: %llu blocks, last start +%.2f, end +%.2f us; per block: fetch %.2f, accept+atomic %.2f, move-in+directions %.2f, "
+                           "t-phase %.2f, rows %.2f, prior %.2f, store %.2f us\n", r, n, (t_last_start - t0) / 100., (t_end - t0) / 100.,
+                           seg[0] / n, seg[1] / n, seg[2] / n, seg[3] / n, seg[4] / n, seg[5] / n, seg[6] / n);
+        }
+    }
+    if (status != RVLL_OK) return status;
+    long long total = 0, evaluated = 0, rounds = 0;
+    std::vector<long long> part(2 * (size_t)nblk);
+    for (int g = 0; g < G; ++g) {
+        HIP_TRY(hipMemcpy(part.data(), ga[(size_t)g].calls_part, sizeof(long long) * part.size(), hipMemcpyDeviceToHost));
+        for (long long b = 0; b < nblk; ++b) { total += part[(size_t)b]; evaluated += part[(size_t)(nblk + b)]; }
+        rounds = std::max(rounds, n_tile[(size_t)g]);
+    }
+    h->walk_rounds_used = (int)std::min<long long>(rounds, 0x7fffffff);
+    if (calls) *calls = total;
+    if (slots) *slots = evaluated;
     return RVLL_OK;
 }
 
@@ -85,6 +399,17 @@ int walk_core(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t m
     // Slim walk (verified-table quantiles only, 4 waves per SIMD) when every Beta / Gamma prior has such a table;
     // walkers it could not finish come back with steps_done < nsteps and are finished by the fat kernel below.
     const bool slim = h->all_direct && !getenv("RVLL_WALK_FAT");
+    // the rounds form (walk_rounds above) takes every walk the slim stage applies to; the single-kernel forms below remain for
+    // the full-solver walk, for the rows the rounds form hands back (deferred at a candidate the tables do not cover), and
+    // behind their switches
+    long long rounds_calls = 0, rounds_slots = 0;
+    bool by_rounds = false;
+    h->walk_rounds_used = 0;
+    if (slim && rounds_wanted()) {
+        rc = walk_rounds(h, K, lstar, nsteps, max_rounds, seed, walker_base, &rounds_calls, &rounds_slots);
+        if (rc == RVLL_OK) by_rounds = true;
+        else if (rc != RVLL_E_UNSUPPORTED) return rc;
+    }
     int spec = h->walk_spec;
     if (const char* e = getenv("RVLL_WALK_SPEC")) spec = atoi(e);       // measurement switch (1: no speculation)
     spec = std::max(1, std::min(spec, rvll::kMaxPointsPerBlock));
@@ -116,13 +441,13 @@ int walk_core(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t m
     const char* renv = getenv("RVLL_WALK_ROWS");
     const bool rows_form = renv && atoi(renv) >= 1 && 3LL * a.PB * a.D <= a.CH;      // (the rows kernels park their candidates in the tile's window)
     const int rows_wide = renv && atoi(renv) == 2 ? rvll::kCuThreads : renv && atoi(renv) == 3 ? 512 : 0;   // 2: one 1024-thread workgroup per CU, 3: two of 512
-    if (two_parts) {
+    if (two_parts && !by_rounds) {
         w.nsteps = std::max(1, rows_form ? nsteps / 8 : nsteps / 4);
         if (const char* e = getenv("RVLL_WALK_FIRST")) w.nsteps = std::max(1, std::min(nsteps - 1, atoi(e)));   // measurement switch
         w.cost = h->d_walk_cost;
     }
-    HIP_TRY(rvll::launch_slice_walk(a, w, !slim, max_cus, st));
-    if (two_parts) {
+    if (!by_rounds) HIP_TRY(rvll::launch_slice_walk(a, w, !slim, max_cus, st));
+    if (two_parts && !by_rounds) {
         const int first = w.nsteps;
         std::vector<int32_t> cost((size_t)K), done((size_t)K), order((size_t)K);
         HIP_TRY(hipMemcpyAsync(cost.data(), h->d_walk_cost, sizeof(int32_t) * (size_t)K, hipMemcpyDeviceToHost, st));
@@ -223,8 +548,8 @@ int walk_core(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t m
     HIP_TRY(hipMemcpyAsync(evaluated, h->d_walk_ncalls, sizeof evaluated, hipMemcpyDeviceToHost, st));
     if (slim) HIP_TRY(hipMemcpyAsync(steps.data(), h->d_walk_steps, sizeof(int32_t) * (size_t)K, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
-    long long total = (long long)evaluated[0];
-    h->walk_evaluated = (long long)evaluated[1];
+    long long total = (long long)evaluated[0] + rounds_calls;
+    h->walk_evaluated = (long long)evaluated[1] + rounds_slots;
     for (int k = 0; k < 6; ++k) h->walk_phase[k] = evaluated[2 + k];
     if (getenv("RVLL_WALK_TILE_DUMP") && evaluated[6])       // diagnostic build: the tile's own phases inside the walk (100 MHz ticks)
         fprintf(stderr, "[walk tile phases, summed over %llu workgroups] stage %llu  decode %llu  items %llu  reduce+write %llu ticks\n",
@@ -508,6 +833,7 @@ int rvll_set_walk_speculation(rvll_handle* h, int32_t max_ahead)
     if (max_ahead < 1 || max_ahead > rvll::kMaxPointsPerBlock)
         return report_error(RVLL_E_INVALID, "max_ahead must be in [1, %d]", rvll::kMaxPointsPerBlock);
     h->walk_spec = max_ahead;
+    h->walk_spec_rounds = max_ahead;
     return RVLL_OK;
 }
 
@@ -515,6 +841,13 @@ int rvll_slice_walk_evaluated(rvll_handle* h, int64_t* evaluated)
 {
     if (!h || !evaluated) return report_error(RVLL_E_INVALID, "null argument");
     *evaluated = h->walk_evaluated;
+    return RVLL_OK;
+}
+
+int rvll_slice_walk_rounds(rvll_handle* h, int32_t* rounds)
+{
+    if (!h || !rounds) return report_error(RVLL_E_INVALID, "null argument");
+    *rounds = h->walk_rounds_used;
     return RVLL_OK;
 }
 

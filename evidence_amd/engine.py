@@ -468,6 +468,12 @@ class GpuRVModel:
         _abi.check(self._lib.rvll_slice_walk_evaluated(self._h, C.byref(n)))
         return int(n.value)
 
+    def slice_walk_rounds(self):
+        """Rounds the last slice_walk / live_step took in the rounds form (include/rvll.h); 0: a single-kernel form walked."""
+        n = C.c_int32(0)
+        _abi.check(self._lib.rvll_slice_walk_rounds(self._h, C.byref(n)))
+        return int(n.value)
+
     def slice_walk_phases(self):
         """Diagnostic library build only (include/rvll.h): ticks per phase of the last slice_walk, summed over workgroups."""
         out = (C.c_uint64 * 6)()

@@ -259,6 +259,11 @@ int rvll_slice_walk_evaluated(rvll_handle* h, int64_t* evaluated);
  * [1] candidates, [2] prior transform + log-L tile, [3] accept / copy / bookkeeping; [4] = number of workgroups;
  * [5] = the longest workgroup life, in ticks. */
 int rvll_slice_walk_phases(rvll_handle* h, uint64_t out[6]);
+/* Which form the last rvll_slice_walk / rvll_live_step took: *rounds = the number of rounds of the ROUNDS form (a round = one
+ * launch that proposes and accepts for a group of walkers + one launch of the batch log-L kernel over the group's candidates,
+ * no host synchronisation in between; the default wherever every Beta / Gamma prior has a verified table), 0 = one of the
+ * single-kernel forms walked (RVLL_WALK_ROUNDS=0, or one of their switches).  Same results either way, bit for bit. */
+int rvll_slice_walk_rounds(rvll_handle* h, int32_t* rounds);
 
 /* ---- nested sampling with the live points resident on the device ----------------------------------------------- */
 /* rvll_slice_walk above takes and returns its walkers through host buffers; a sampler built on it ships three row sets

@@ -14,7 +14,7 @@ FLAGS = "-O3 -std=c++17 -fPIC -ffp-contract=off --offload-arch=gfx950 -fvisibili
 
 def main():
     rows = []
-    for src, extra in (("rvll_kernels.hip", ""), ("rvll_walk.hip", "-mllvm -disable-machine-licm"), ("rvll_fip.hip", "")):
+    for src, extra in (("rvll_kernels.hip", ""), ("rvll_walk.hip", "-mllvm -disable-machine-licm"), ("rvll_live.hip", ""), ("rvll_fip.hip", "")):
         cmd = f"/opt/rocm/bin/hipcc {FLAGS} {extra} -Rpass-analysis=kernel-resource-usage -c {src} -o /dev/null"
         err = subprocess.run(cmd, shell=True, cwd=CSRC, capture_output=True, text=True).stderr
         cur = None

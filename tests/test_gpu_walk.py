@@ -281,6 +281,47 @@ def test_rows_form_of_the_second_part_is_the_queue_walk(gpu_required, monkeypatc
             assert (runs["rows"][2] > lstar).all()
 
 
+def test_rounds_form_is_the_single_kernel_walk(gpu_required, monkeypatch):
+    """The default form of the walk (round 4) is a sequence of ROUNDS — per group of walkers one launch that accepts /
+    shrinks and proposes, one launch of the batch log-L kernel over the group's compacted candidates, walker state resident
+    in HBM (rvll_rounds.hip) — instead of one kernel that keeps its walkers in LDS.  How the walkers are grouped (one group:
+    step and tiles in launches of their own; more: one group's step inside another's tile launch), how many candidates a
+    walker gets ahead, how deep the host keeps the queue: none of it
+    shows in the results, which are those of the single-kernel walk (RVLL_WALK_ROUNDS=0) bit for bit — end points, theta,
+    log-L, the number of likelihood calls — with and without walkers deferred to the full-solver pass on the way."""
+    knobs = ("RVLL_WALK_ROUNDS", "RVLL_ROUNDS_GROUPS", "RVLL_ROUNDS_FREE", "RVLL_ROUNDS_DEPTH", "RVLL_WALK_SPEC")
+    variants = [{}, {"RVLL_ROUNDS_GROUPS": "1"}, {"RVLL_ROUNDS_GROUPS": "3"}, {"RVLL_ROUNDS_GROUPS": "4", "RVLL_WALK_SPEC": "1"},
+                {"RVLL_WALK_SPEC": "16", "RVLL_ROUNDS_FREE": "100000"}, {"RVLL_ROUNDS_FREE": "1", "RVLL_ROUNDS_DEPTH": "1"},
+                {"RVLL_ROUNDS_DEPTH": "9"}]
+    for cfg, k, nsteps in ((3, 5000, 9), (3, 131, 21), (1, 40, 7), (5, 600, 5)):
+        w = make_workload(cfg)
+        with GpuRVModel(w.fixedpardict, w.table, w.parnames, priordict=w.priordict()) as m:
+            cube, theta, logl, lstar, chol = _start(m, w, k, seed=70 + cfg, quantile=0.6)
+            wr = wrapped_params(m.parnames)
+            for umax in ((30.0, 1.0) if cfg == 3 else (30.0,)):
+                m.set_slim_table_range(umax)
+                monkeypatch.setenv("RVLL_WALK_ROUNDS", "0")
+                ref = m.slice_walk(cube, theta, logl, lstar, chol, wr, nsteps=nsteps, seed=13)
+                assert m.slice_walk_rounds() == 0
+                monkeypatch.delenv("RVLL_WALK_ROUNDS")
+                for env in variants:
+                    for key, val in env.items():
+                        monkeypatch.setenv(key, val)
+                    got = m.slice_walk(cube, theta, logl, lstar, chol, wr, nsteps=nsteps, seed=13)
+                    rounds, slots = m.slice_walk_rounds(), m.slice_walk_evaluated()
+                    for key in env:
+                        monkeypatch.delenv(key)
+                    assert all(np.array_equal(a, b) for a, b in zip(got[:3], ref[:3])) and got[3] == ref[3], (cfg, k, umax, env)
+                    assert rounds >= (nsteps if umax == 30.0 else 1) and slots >= got[3], (cfg, k, umax, env)       # it did walk in rounds
+                    if env.get("RVLL_WALK_SPEC") == "1" and umax == 30.0:
+                        assert slots == got[3]                                             # no candidates ahead: every slot a call
+            m.set_slim_table_range(30.0)
+            th_chk, ll_chk = m.prior_loglike_batch(ref[0])
+            assert np.array_equal(th_chk, ref[1]) and np.array_equal(ll_chk, ref[2]) and (ref[2] > lstar).all()
+    for key in knobs:
+        assert key not in __import__("os").environ
+
+
 def test_queue_serves_rows_with_nothing_left_to_do_and_a_ragged_last_workgroup(gpu_required, monkeypatch):
     """Sizes around the queue's edges: fewer walkers than one workgroup holds, a walker count that is not a multiple of
     the group size, one workgroup serving every row."""
