@@ -507,6 +507,8 @@ int rvll_destroy(rvll_handle* h)
     dev_free(h->d_rounds); dev_free(h->d_walk_dirs);
     if (h->pin_rounds) (void)hipHostFree(h->pin_rounds);
     if (h->ev_rounds) (void)hipEventDestroy(h->ev_rounds);
+    for (auto& s : h->rounds_streams) if (s) (void)hipStreamDestroy(s);
+    for (auto& e : h->ev_chain) if (e) (void)hipEventDestroy(e);
     for (auto& e : h->marks) if (e) (void)hipEventDestroy(e);
     if (h->srv_stream) (void)hipStreamDestroy(h->srv_stream);
     if (h->srv) (void)hipHostFree(h->srv);

@@ -151,6 +151,8 @@ struct rvll_handle {
     unsigned long long* pin_rounds = nullptr;   // [kMaxLanes]
     unsigned long long* pin_rounds_dev = nullptr;
     hipEvent_t ev_rounds = nullptr;             // orders the groups' streams behind lane 0
+    hipEvent_t ev_chain[kMaxLanes] = {};        // group g's step of a round has been issued to the device (the next group's step waits for it)
+    hipStream_t rounds_streams[kMaxLanes] = {}; // the groups' streams, at DIFFERENT priorities (walk_rounds)
     int walk_rounds_used = 0;                   // rounds the last walk took (0: it ran in one of the single-kernel forms)
     long long walk_evaluated = 0;               // tile slots the last rvll_slice_walk evaluated (>= its ncalls)
     unsigned long long walk_phase[6] = {};      // diagnostic build (make walktrace): 100 MHz ticks per phase, summed over workgroups; workgroups

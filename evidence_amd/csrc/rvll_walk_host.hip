@@ -43,14 +43,18 @@ int walk_reserve(rvll_handle* h, int64_t K)
     return RVLL_OK;
 }
 
-// ---- the walk as rounds of launches (rvll_rounds.hip) ----------------------------------------------------------------
-// Which walks take it: RVLL_WALK_ROUNDS = 0 never / 1 whenever the slim prior stage applies; by default every walk the slim
-// stage applies to, unless one of the switches that select a single-kernel form is set (RVLL_WALK_QUEUE / _PARTS / _ROWS /
-// _FAT: the tests and the measurements of those forms).
-bool rounds_wanted()
+// ---- the walk as rounds of launches (rvll_rounds.h, rvll_kernels.hip) ----------------------------------------------------
+// Which walks take it: RVLL_WALK_ROUNDS = 0 never / 1 whenever the slim prior stage applies.  By default the walks it was
+// measured to win (profiles/r04_rounds_sizes.txt, cfg3, nested sampling end to end, calls/s inside the walk against the
+// single-kernel form): 8192 walkers 1.23 against 1.05e8, 16384: 1.72 against 1.62e8 — and not the ones it loses: 4096 walkers
+// and fewer (a round's fixed ~35 us against a workgroup iteration of the single kernel: 5.2 against 5.8e7), 32768 (1.86 against
+// 1.90e8: the single kernel's queue has enough rows per slot there).  None of the switches that select a single-kernel form
+// may be set (RVLL_WALK_QUEUE / _PARTS / _ROWS / _FAT: the tests and the measurements of those forms).
+bool rounds_wanted(int64_t K)
 {
     if (const char* e = getenv("RVLL_WALK_ROUNDS")) return atoi(e) != 0;
-    return !getenv("RVLL_WALK_QUEUE") && !getenv("RVLL_WALK_PARTS") && !getenv("RVLL_WALK_ROWS") && !getenv("RVLL_WALK_FAT");
+    if (getenv("RVLL_WALK_QUEUE") || getenv("RVLL_WALK_PARTS") || getenv("RVLL_WALK_ROWS") || getenv("RVLL_WALK_FAT")) return false;
+    return K >= 6144 && K <= 24576;
 }
 
 // The K rows of d_walk_u / d_walk_theta / d_walk_logl (chol, wrapped uploaded) walked in rounds: G groups of rows; a group's
@@ -69,12 +73,15 @@ int walk_rounds(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t
     int spec = h->walk_spec_rounds;
     if (const char* e = getenv("RVLL_WALK_SPEC")) spec = atoi(e);       // measurement switch (1: no candidates ahead)
     spec = std::max(1, std::min(spec, rvll::kMaxPointsPerBlock));
-    int G = 2;
+    int G = 3;                                                          // (measured at cfg3: 2: 1.64, 3: 1.72, 4: 1.67e8 calls/s; profiles/r04_rounds_sweep.txt)
     if (const char* e = getenv("RVLL_ROUNDS_GROUPS")) G = atoi(e);
     G = (int)std::max<long long>(1, std::min<long long>(std::min(G, kMaxLanes), K));
-    // slots a round holds at the log-L kernel's latency floor — about two wave rounds per wave of the chip, shared by the
-    // groups — and with it the capacity of a group's candidate array
-    long long c_free = std::max<long long>(256, (long long)h->n_cu * 2048 / std::max(1, h->Ne) / G);
+    // Slots a round may hold before walkers stop getting candidates AHEAD: while a group lists fewer walkers than this, the free
+    // slots go to its walkers' next candidates (consumed in order: the results do not change).  A round costs ~35 us whatever it
+    // holds (a step, a launch, a tile's prologue and last wave round) plus ~3 ns a slot, and a walk is a chain of such rounds:
+    // below ~6000 slots at 200 epochs a round is cheaper filled with candidates of which two in three go unused than run again
+    // (measured, 16384 walkers: 1300: 1.50, 2600: 1.61, 4000: 1.68, 6000: 1.72, 8000: 1.71e8 calls/s).  Scaled by the epochs.
+    long long c_free = std::max<long long>(256, (long long)h->n_cu * 4608 / std::max(1, h->Ne));
     if (const char* e = getenv("RVLL_ROUNDS_FREE")) c_free = std::max(1, atoi(e));
     // How the rounds are issued (RVLL_ROUNDS_MODE / RVLL_ROUNDS_FORM, measurement switches):
     //   fused    one stream; every launch = one group's tiles (256-thread form) + another group's step (rounds_kernel)
@@ -82,7 +89,7 @@ int walk_rounds(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t
     const char* menv = getenv("RVLL_ROUNDS_MODE");
     const char* fenv = getenv("RVLL_ROUNDS_FORM");
     const bool fused = menv ? !strcmp(menv, "fused") : false;
-    const bool cu_form = !fused && (fenv ? !strcmp(fenv, "cu") : true);
+    const bool cu_form = !fused && fenv && !strcmp(fenv, "cu");
     rvll::LoglikeArgs a;
     long long per = (K + G - 1) / G;
     int rc = build_args(h, nullptr, nullptr, nullptr, std::max(per, c_free), &a);
@@ -235,11 +242,31 @@ int walk_rounds(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t
     const auto t_walk0 = steady_clock::now();
     long long launch_ns = 0, n_launch = 0;
     unsigned long long seen_sum = 0;
+    // The groups' streams: the handle's lanes (RVLL_ROUNDS_PRIO=1, a measurement switch: streams of DIFFERENT priorities — it did
+    // not keep the groups out of lock step: 1.45 against 1.51e8 calls/s)
+    std::vector<hipStream_t> gs((size_t)G, h->compute);
+    const char* cenv = getenv("RVLL_ROUNDS_CHAIN");
+    const bool chain = !fused && G > 1 && cenv && atoi(cenv) != 0;       // measured: 1.57 against 1.71e8 calls/s unchained
+    if (chain)
+        for (int g = 0; g < G; ++g)
+            if (!h->ev_chain[g]) HIP_TRY(hipEventCreateWithFlags(&h->ev_chain[g], hipEventDisableTiming));
     if (!fused && G > 1) {
-        // the groups' streams start behind what lane 0 holds (uploads, the live step's gathers, the zeroing above)
+        const char* penv = getenv("RVLL_ROUNDS_PRIO");
+        const bool prio = penv && atoi(penv) != 0;
+        int lo_p = 0, hi_p = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);      // (numerically: hi_p <= lo_p)
+        for (int g = 0; g < G; ++g) {
+            if (!prio) { gs[(size_t)g] = h->lanes[g]; continue; }
+            if (!h->rounds_streams[g]) {
+                const int p = std::max(hi_p, std::min(lo_p, hi_p + g));
+                HIP_TRY(hipStreamCreateWithPriority(&h->rounds_streams[g], hipStreamNonBlocking, p));
+            }
+            gs[(size_t)g] = h->rounds_streams[g];
+        }
+        // they start behind what lane 0 holds (uploads, the live step's gathers, the zeroing above)
         if (!h->ev_rounds) HIP_TRY(hipEventCreateWithFlags(&h->ev_rounds, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(h->ev_rounds, h->compute));
-        for (int g = 1; g < G; ++g) HIP_TRY(hipStreamWaitEvent(h->lanes[g], h->ev_rounds, 0));
+        for (int g = 0; g < G; ++g) if (gs[(size_t)g] != h->compute) HIP_TRY(hipStreamWaitEvent(gs[(size_t)g], h->ev_rounds, 0));
     }
     auto tiles_of = [&](int g, int r, hipStream_t s) -> hipError_t {
         ta[(size_t)g].ring_entry = ga[(size_t)g].ring + 2 * (r % rvll::kRoundsRing);
@@ -287,6 +314,42 @@ int walk_rounds(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t
                 turn = (turn + 1) % G;
                 any = true;
             }
+        } else if (chain) {
+            // (RVLL_ROUNDS_CHAIN=1, a measurement switch.)  Left to themselves the groups fall into lock step: all step together
+            // (the chip idle for a step's 20 us), then all run their tiles together.  Here the steps are CHAINED: group g's step
+            // of a round waits (an event, on the device) for group g - 1's step of that round — it starts when g - 1's tiles do
+            // and runs beside them — and the host issues a round for all groups at once.  Slower: the groups then all wait for
+            // the slowest of them, and every link adds an event's latency.
+            bool ready = true;
+            for (int g = 0; g < G; ++g) {
+                if (done[(size_t)g]) continue;
+                const unsigned long long p = __atomic_load_n(&h->pin_rounds[g], __ATOMIC_ACQUIRE);
+                const long long pub = (long long)(p >> 32);
+                sum += p;
+                if (pub > 0 && (unsigned)p == 0u) { done[(size_t)g] = 1; ++ndone; continue; }
+                if (n_tile[(size_t)g] - pub >= depth) ready = false;
+            }
+            if (ready && ndone < G) {
+                int prev = -1;
+                const auto tl0 = steady_clock::now();
+                for (int g = 0; g < G && status == RVLL_OK; ++g) {
+                    if (done[(size_t)g]) continue;
+                    if (n_tile[(size_t)g] >= r_max) { status = report_error(RVLL_E_HIP, "rounds walk: group %d did not finish in %lld rounds", g, r_max); break; }
+                    const int r = (int)n_tile[(size_t)g];
+                    hipError_t e = hipSuccess;
+                    if (prev >= 0) e = hipStreamWaitEvent(gs[(size_t)g], h->ev_chain[prev], 0);
+                    if (e == hipSuccess) e = rvll::launch_rounds_step(ga[(size_t)g], r, gs[(size_t)g]);
+                    if (e == hipSuccess) e = hipEventRecord(h->ev_chain[g], gs[(size_t)g]);
+                    if (e == hipSuccess) e = tiles_of(g, r, gs[(size_t)g]);
+                    if (e != hipSuccess) { status = report_error(RVLL_E_HIP, "rounds walk launch failed: %s", hipGetErrorString(e)); break; }
+                    n_step[(size_t)g] += 1;
+                    n_tile[(size_t)g] += 1;
+                    n_launch += 2;
+                    prev = g;
+                    any = true;
+                }
+                launch_ns += duration_cast<nanoseconds>(steady_clock::now() - tl0).count();
+            }
         } else {
             for (int g = 0; g < G && status == RVLL_OK; ++g) {
                 if (done[(size_t)g]) continue;
@@ -298,8 +361,8 @@ int walk_rounds(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t
                 if (n_tile[(size_t)g] >= r_max) { status = report_error(RVLL_E_HIP, "rounds walk: group %d did not finish in %lld rounds", g, r_max); break; }
                 const int r = (int)n_tile[(size_t)g];
                 const auto tl0 = steady_clock::now();
-                hipError_t e = rvll::launch_rounds_step(ga[(size_t)g], r, h->lanes[g]);
-                if (e == hipSuccess) e = tiles_of(g, r, h->lanes[g]);
+                hipError_t e = rvll::launch_rounds_step(ga[(size_t)g], r, gs[(size_t)g]);
+                if (e == hipSuccess) e = tiles_of(g, r, gs[(size_t)g]);
                 launch_ns += duration_cast<nanoseconds>(steady_clock::now() - tl0).count();  n_launch += 2;
                 if (e != hipSuccess) { status = report_error(RVLL_E_HIP, "rounds walk launch failed: %s", hipGetErrorString(e)); break; }
                 n_step[(size_t)g] += 1;
@@ -315,7 +378,7 @@ int walk_rounds(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t
         std::this_thread::yield();
     }
     for (int g = 0; g < (fused ? 1 : G); ++g) {
-        const hipError_t e = hipStreamSynchronize(h->lanes[g]);
+        const hipError_t e = hipStreamSynchronize(gs[(size_t)g]);
         if (e != hipSuccess && status == RVLL_OK) status = report_error(RVLL_E_HIP, "rounds walk: %s", hipGetErrorString(e));
     }
     if (getenv("RVLL_WALK_GEOM_DUMP"))
@@ -405,7 +468,7 @@ int walk_core(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t m
     long long rounds_calls = 0, rounds_slots = 0;
     bool by_rounds = false;
     h->walk_rounds_used = 0;
-    if (slim && rounds_wanted()) {
+    if (slim && rounds_wanted(K)) {
         rc = walk_rounds(h, K, lstar, nsteps, max_rounds, seed, walker_base, &rounds_calls, &rounds_slots);
         if (rc == RVLL_OK) by_rounds = true;
         else if (rc != RVLL_E_UNSUPPORTED) return rc;

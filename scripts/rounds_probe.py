@@ -10,7 +10,7 @@ from evidence_amd import GpuRVModel
 from evidence_amd.callbacks import wrapped_params
 from evidence_amd.synthetic import make_workload
 
-SWITCHES = ("RVLL_WALK_ROUNDS", "RVLL_ROUNDS_GROUPS", "RVLL_ROUNDS_FREE", "RVLL_ROUNDS_DEPTH", "RVLL_WALK_SPEC", "RVLL_ROUNDS_W", "RVLL_ROUNDS_PB", "RVLL_ROUNDS_MODE", "RVLL_ROUNDS_FORM")
+SWITCHES = ("RVLL_WALK_ROUNDS", "RVLL_ROUNDS_GROUPS", "RVLL_ROUNDS_FREE", "RVLL_ROUNDS_DEPTH", "RVLL_WALK_SPEC", "RVLL_ROUNDS_W", "RVLL_ROUNDS_PB", "RVLL_ROUNDS_MODE", "RVLL_ROUNDS_FORM", "RVLL_ROUNDS_PRIO", "RVLL_ROUNDS_CHAIN")
 
 def setenv(env):
     for k in SWITCHES:

@@ -282,17 +282,21 @@ def test_rows_form_of_the_second_part_is_the_queue_walk(gpu_required, monkeypatc
 
 
 def test_rounds_form_is_the_single_kernel_walk(gpu_required, monkeypatch):
-    """The default form of the walk (round 4) is a sequence of ROUNDS — per group of walkers one launch that accepts /
-    shrinks and proposes, one launch of the batch log-L kernel over the group's compacted candidates, walker state resident
-    in HBM (rvll_rounds.hip) — instead of one kernel that keeps its walkers in LDS.  How the walkers are grouped (one group:
-    step and tiles in launches of their own; more: one group's step inside another's tile launch), how many candidates a
-    walker gets ahead, how deep the host keeps the queue: none of it
-    shows in the results, which are those of the single-kernel walk (RVLL_WALK_ROUNDS=0) bit for bit — end points, theta,
-    log-L, the number of likelihood calls — with and without walkers deferred to the full-solver pass on the way."""
-    knobs = ("RVLL_WALK_ROUNDS", "RVLL_ROUNDS_GROUPS", "RVLL_ROUNDS_FREE", "RVLL_ROUNDS_DEPTH", "RVLL_WALK_SPEC")
-    variants = [{}, {"RVLL_ROUNDS_GROUPS": "1"}, {"RVLL_ROUNDS_GROUPS": "3"}, {"RVLL_ROUNDS_GROUPS": "4", "RVLL_WALK_SPEC": "1"},
+    """The walk has a second form (round 4): a sequence of ROUNDS — per group of walkers one launch that accepts / shrinks,
+    proposes and prior-transforms (directions of all moves made ahead of time), one launch of the batch theta -> log-L tiles
+    over the group's compacted candidates; walker state resident in HBM (csrc/rvll_rounds.h) — instead of one kernel that
+    keeps its walkers in LDS.  It is what walks of 6144 .. 24576 rows take by default (where it was measured faster,
+    profiles/r04_rounds_sizes.txt); RVLL_WALK_ROUNDS=1 / 0 forces / forbids it.  How the walkers are grouped, how the rounds
+    are issued (a stream per group, chained or not; one stream with one group's step inside another's tile launch), which
+    form the tiles take, how many candidates a walker gets ahead, how deep the host keeps the queues: none of it shows in
+    the results, which are those of the single-kernel walk bit for bit — end points, theta, log-L, the number of likelihood
+    calls — with and without walkers deferred to the full-solver pass on the way."""
+    knobs = ("RVLL_WALK_ROUNDS", "RVLL_ROUNDS_GROUPS", "RVLL_ROUNDS_FREE", "RVLL_ROUNDS_DEPTH", "RVLL_WALK_SPEC", "RVLL_ROUNDS_FORM",
+             "RVLL_ROUNDS_MODE", "RVLL_ROUNDS_CHAIN", "RVLL_ROUNDS_PRIO", "RVLL_ROUNDS_W", "RVLL_ROUNDS_PB")
+    variants = [{}, {"RVLL_ROUNDS_GROUPS": "1"}, {"RVLL_ROUNDS_GROUPS": "2", "RVLL_ROUNDS_FORM": "cu"}, {"RVLL_ROUNDS_GROUPS": "4", "RVLL_WALK_SPEC": "1"},
+                {"RVLL_ROUNDS_MODE": "fused", "RVLL_ROUNDS_GROUPS": "2"}, {"RVLL_ROUNDS_CHAIN": "1"}, {"RVLL_ROUNDS_PRIO": "1", "RVLL_ROUNDS_W": "16"},
                 {"RVLL_WALK_SPEC": "16", "RVLL_ROUNDS_FREE": "100000"}, {"RVLL_ROUNDS_FREE": "1", "RVLL_ROUNDS_DEPTH": "1"},
-                {"RVLL_ROUNDS_DEPTH": "9"}]
+                {"RVLL_ROUNDS_DEPTH": "9", "RVLL_ROUNDS_PB": "3"}]
     for cfg, k, nsteps in ((3, 5000, 9), (3, 131, 21), (1, 40, 7), (5, 600, 5)):
         w = make_workload(cfg)
         with GpuRVModel(w.fixedpardict, w.table, w.parnames, priordict=w.priordict()) as m:
@@ -303,8 +307,8 @@ def test_rounds_form_is_the_single_kernel_walk(gpu_required, monkeypatch):
                 monkeypatch.setenv("RVLL_WALK_ROUNDS", "0")
                 ref = m.slice_walk(cube, theta, logl, lstar, chol, wr, nsteps=nsteps, seed=13)
                 assert m.slice_walk_rounds() == 0
-                monkeypatch.delenv("RVLL_WALK_ROUNDS")
                 for env in variants:
+                    monkeypatch.setenv("RVLL_WALK_ROUNDS", "1")
                     for key, val in env.items():
                         monkeypatch.setenv(key, val)
                     got = m.slice_walk(cube, theta, logl, lstar, chol, wr, nsteps=nsteps, seed=13)
@@ -315,9 +319,24 @@ def test_rounds_form_is_the_single_kernel_walk(gpu_required, monkeypatch):
                     assert rounds >= (nsteps if umax == 30.0 else 1) and slots >= got[3], (cfg, k, umax, env)       # it did walk in rounds
                     if env.get("RVLL_WALK_SPEC") == "1" and umax == 30.0:
                         assert slots == got[3]                                             # no candidates ahead: every slot a call
+                monkeypatch.delenv("RVLL_WALK_ROUNDS")
             m.set_slim_table_range(30.0)
             th_chk, ll_chk = m.prior_loglike_batch(ref[0])
             assert np.array_equal(th_chk, ref[1]) and np.array_equal(ll_chk, ref[2]) and (ref[2] > lstar).all()
+    # which form a walk takes by default goes by its size
+    w = make_workload(3)
+    with GpuRVModel(w.fixedpardict, w.table, w.parnames, priordict=w.priordict()) as m:
+        cube, theta, logl, lstar, chol = _start(m, w, 16000, seed=77, quantile=0.5)
+        wr = wrapped_params(m.parnames)
+        big = m.slice_walk(cube, theta, logl, lstar, chol, wr, nsteps=5, seed=3)
+        assert m.slice_walk_rounds() >= 5 and len(cube) >= 6144
+        small = m.slice_walk(cube[:3000], theta[:3000], logl[:3000], lstar, chol, wr, nsteps=5, seed=3)
+        assert m.slice_walk_rounds() == 0
+        monkeypatch.setenv("RVLL_WALK_ROUNDS", "0")
+        ref = m.slice_walk(cube, theta, logl, lstar, chol, wr, nsteps=5, seed=3)
+        monkeypatch.delenv("RVLL_WALK_ROUNDS")
+        assert all(np.array_equal(a, b) for a, b in zip(big[:3], ref[:3])) and big[3] == ref[3]
+        assert all(np.array_equal(a[:3000], b) for a, b in zip(ref[:3], small[:3]))       # (rows walk alike whatever walks beside them)
     for key in knobs:
         assert key not in __import__("os").environ
 
