@@ -163,6 +163,11 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
             S = max(1, min(S, w.max_rounds - (st == 0 ? 0 : round_of[pl])));
         }
         if (slot) nsp_of[pl] = S;
+        // (the lanes of this wave read each other's word next: a wave-scope release + barrier, so that the order holds by the
+        // memory model and not only by how the hardware happens to run a wave — ADVICE r3)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         int f = 0;
         for (int k = 0; k < pl && k < nw; ++k) f += nsp_of[k];
         if (listed) first_of[pl] = f;
@@ -531,6 +536,9 @@ void slice_walk_rows_kernel(const LoglikeArgs a, const WalkArgs w)
             S = max(1, min(S, w.max_rounds - (st == 0 ? 0 : round_of[pl])));
         }
         if (slot) nsp_of[pl] = S;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (as in slice_walk_kernel: the lanes read each other's word next)
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         int f = 0;
         for (int k = 0; k < pl && k < PB; ++k) f += nsp_of[k];
         if (listed) first_of[pl] = f;

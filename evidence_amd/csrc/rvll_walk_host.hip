@@ -737,6 +737,10 @@ int rvll_live_init(rvll_handle* h, const double* cube, int64_t N, double* logl_o
     if (rc) return rc;
     if (!h->have_priors) return report_error(RVLL_E_NOPRIORS, "rvll_set_priors has not been called");
     if (N < 1 || N >= (1LL << 31) || !cube) return report_error(RVLL_E_INVALID, "rvll_live_init: bad arguments");
+    // a new run starts here: whatever fails below, no earlier run's live set is left looking valid (rvll_live_step and
+    // rvll_live_get refuse live_n = 0) — live_n is set again as the last thing, on success
+    h->live_n = 0;
+    h->dead_n = 0;
     const size_t D = (size_t)std::max(1, h->L.ndim);
     rc = rvll_dev_upload_cube(h, cube, N);
     if (rc) return rc;
@@ -781,6 +785,16 @@ int rvll_live_step(rvll_handle* h, const int32_t* order, int64_t kdead, const in
     if (rc) return rc;
     for (int64_t i = 0; i < N; ++i)
         if (order[i] < 0 || order[i] >= N) return report_error(RVLL_E_INVALID, "rvll_live_step: order[%lld] out of range", (long long)i);
+    {
+        // the dying rows are scattered into in parallel and appended to the dead store: a row listed twice would race and be counted twice
+        std::vector<uint64_t> seen(((size_t)N + 63) / 64, 0);
+        for (int64_t i = 0; i < kdead; ++i) {
+            uint64_t& word = seen[(size_t)order[i] >> 6];
+            const uint64_t bit = 1ull << (order[i] & 63);
+            if (word & bit) return report_error(RVLL_E_INVALID, "rvll_live_step: row %d is listed twice among the dying rows", (int)order[i]);
+            word |= bit;
+        }
+    }
     for (int64_t i = 0; i < kdead; ++i)
         if (start[i] < 0 || start[i] >= N) return report_error(RVLL_E_INVALID, "rvll_live_step: start[%lld] out of range", (long long)i);
     const size_t D = (size_t)h->L.ndim;
@@ -797,18 +811,29 @@ int rvll_live_step(rvll_handle* h, const int32_t* order, int64_t kdead, const in
         const long long cap = std::max<long long>(2 * h->dead_cap, h->dead_n + 4 * kdead);
         double *nt = nullptr, *nl = nullptr;
         HIP_TRY(hipMalloc(&nt, sizeof(double) * D * (size_t)cap));
-        HIP_TRY(hipMalloc(&nl, sizeof(double) * (size_t)cap));
+        {
+            const hipError_t e = hipMalloc(&nl, sizeof(double) * (size_t)cap);
+            if (e != hipSuccess) {
+                (void)hipFree(nt);
+                return report_error(e == hipErrorOutOfMemory ? RVLL_E_NOMEM : RVLL_E_HIP, "rvll_live_step: dead store: %s", hipGetErrorString(e));
+            }
+        }
         if (h->dead_n) {
-            HIP_TRY(hipMemcpyAsync(nt, h->d_dead_theta, sizeof(double) * D * (size_t)h->dead_n, hipMemcpyDeviceToDevice, st));
-            HIP_TRY(hipMemcpyAsync(nl, h->d_dead_logl, sizeof(double) * (size_t)h->dead_n, hipMemcpyDeviceToDevice, st));
-            HIP_TRY(hipStreamSynchronize(st));
+            hipError_t e = hipMemcpyAsync(nt, h->d_dead_theta, sizeof(double) * D * (size_t)h->dead_n, hipMemcpyDeviceToDevice, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(nl, h->d_dead_logl, sizeof(double) * (size_t)h->dead_n, hipMemcpyDeviceToDevice, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) {
+                (void)hipFree(nt); (void)hipFree(nl);
+                return report_error(RVLL_E_HIP, "rvll_live_step: dead store: %s", hipGetErrorString(e));
+            }
         }
         dev_free(h->d_dead_theta); dev_free(h->d_dead_logl);
         h->d_dead_theta = nt; h->d_dead_logl = nl; h->dead_cap = cap;
     }
     HIP_TRY(rvll::launch_gather_rows(h->d_live_theta, d_order, kdead, Di, h->d_dead_theta + (size_t)h->dead_n * D, st));
     HIP_TRY(rvll::launch_gather_rows(h->d_live_logl, d_order, kdead, 1, h->d_dead_logl + h->dead_n, st));
-    h->dead_n += kdead;
+    // (dead_n moves on when the step has succeeded, at the bottom: a step that fails below — a covariance that is not positive
+    // definite, a walk that fails — leaves the dead store as it was, so a retry does not append the same rows twice)
     // whitening: the caller's factor, or the covariance of the surviving rows order[kdead .. N) summed on the device (in a
     // fixed order) and factored here (19 x 19: host arithmetic; + 1e-14 on the diagonal as evidence_amd/nested.py adds)
     std::vector<double> factor(D * D, 0.);
@@ -850,6 +875,7 @@ int rvll_live_step(rvll_handle* h, const int32_t* order, int64_t kdead, const in
     HIP_TRY(rvll::launch_scatter_rows(h->d_walk_logl, d_order, kdead, 1, h->d_live_logl, st));
     HIP_TRY(hipMemcpyAsync(logl_new, h->d_walk_logl, sizeof(double) * (size_t)kdead, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    h->dead_n += kdead;
     return RVLL_OK;
 }
 

@@ -88,3 +88,34 @@ def test_a_rank_that_dies_after_a_measurement_completed_does_not_take_that_line_
     assert "last completed measurement" in lines[0]["config"]["note"] and "sharded configs" in lines[0]["config"]["note"]
     assert r.returncode != 0                                 # a run in which a rank failed does not exit 0
     assert "rank 1 exited with code 7" in r.stderr
+
+
+def test_bench_gpus_8_the_drivers_node_size():
+    """The run the driver makes on an 8-GPU node and this pool cannot rehearse on hardware: eight ranks through
+    the self-launcher and the rendezvous, ONE line, rc 0, the two BASELINE configurations that name 8 GPUs sharded as they
+    name them — cfg4 8192 rows a rank, cfg5 16384."""
+    r, lines = _run(["--gpus", "8", "--steps", "4", "--warmup", "1", "--no-cpu"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1
+    d = lines[0]
+    assert d["n_gpus"] == 8 and d["steps"] == 4 and d["scaling"] == "weak" and d["value"] > 0
+    cfg = d["config"]
+    assert cfg["devices"] == [0] * 8 and cfg["shared_device"] is True and cfg["launched_by"] == "bench.py itself"
+    assert cfg["allgather"] == "host-socket-fallback" and cfg["torch_in_process"] is False
+    sc = d["sharded_configs"]
+    assert sc["cfg4"]["live_points_total"] == 65536 and sc["cfg4"]["live_points_per_gpu"] == 8192 and sc["cfg4"]["evals_per_s"] > 0
+    assert sc["cfg5"]["live_points_total"] == 131072 and sc["cfg5"]["live_points_per_gpu"] == 16384
+    for prec in ("fp64", "mixed", "fp32"):
+        assert sc["cfg5"][prec]["ms_per_step"] > 0
+    assert "extras_failed" not in d
+
+
+def test_a_rank_of_eight_that_dies_mid_phase_does_not_take_the_line_with_it():
+    # rank 5 of 8 leaves after the headline was measured and verified: the line still goes out (rank 0 reports first), rc != 0
+    r, lines = _run(["--gpus", "8", "--steps", "4", "--warmup", "1", "--no-cpu"], RVLL_STUB_DIE_RANK="5", RVLL_STUB_DIE_AFTER="112")
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 8
+    assert r.returncode != 0 and "rank 5 exited with code 7" in r.stderr
+    if lines[0]["value"] > 0:
+        assert "last completed measurement" in lines[0]["config"]["note"]
+    else:
+        assert lines[0]["config"]["allgather"] == "rccl-hung"

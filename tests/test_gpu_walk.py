@@ -416,6 +416,30 @@ def test_live_step_api_contract(gpu_required):
     d0 = cube[keep] - cube[keep].mean(axis=0)
     want = np.linalg.cholesky(d0.T @ d0 / (len(keep) - 1) + 1e-14 * np.eye(m.ndim))
     assert np.allclose(chol, want, rtol=1e-10, atol=1e-13) and np.allclose(np.triu(chol, 1), 0.0)
+    # a step that fails leaves the run as it was: a dying row listed twice is refused before anything is touched; a
+    # covariance that cannot be factored (a NaN among the surviving rows) fails AFTER the dying rows were copied to the dead
+    # store — which must not count them, or a retry would append them again
+    with GpuRVModel(w.fixedpardict, w.table, w.parnames, priordict=w.priordict()) as m:
+        rng = np.random.default_rng(5)
+        cube = rng.random((600, m.ndim))
+        logl = m.live_init(cube)
+        order = np.argsort(logl, kind="stable")
+        start = order[200:][rng.integers(0, 400, 200)]
+        twice = order.copy(); twice[1] = twice[0]
+        with pytest.raises(Exception, match="listed twice"):
+            m.live_step(twice, 200, start, logl[order[199]], wrapped_params(m.parnames), nsteps=3, seed=1)
+        assert m.live_dead_count() == 0
+        new, used = m.live_step(order, 200, start, logl[order[199]], wrapped_params(m.parnames), nsteps=3, seed=1)
+        assert m.live_dead_count() == 200
+        bad = cube.copy(); bad[7, 2] = np.nan
+        logl_bad = m.live_init(bad)                                   # (a new run: the dead store is empty again)
+        assert m.live_dead_count() == 0
+        fin = np.where(np.isfinite(logl_bad), logl_bad, -1e300)
+        order = np.argsort(fin, kind="stable")                        # the NaN row dies first only if listed first: keep it among the survivors
+        order = np.concatenate([order[order != 7], [7]])
+        with pytest.raises(Exception, match="positive definite"):
+            m.live_step(order, 100, order[100:300], fin[order[99]], wrapped_params(m.parnames), nsteps=3, seed=1)
+        assert m.live_dead_count() == 0                               # nothing was appended by the step that failed
     with GpuRVModel(w.fixedpardict, w.table, w.parnames, priordict=w.priordict()) as m:
         with pytest.raises(RuntimeError, match="live_init"):
             m.live_step(np.arange(5), 2, np.array([3, 4]), 0.0)

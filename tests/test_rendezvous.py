@@ -1,5 +1,5 @@
-"""CPU: the torch-free control plane of the one-process-per-GPU runs (evidence_amd/rendezvous.py) at world sizes 2
-and 3 — the exchange bench.py and the sharded samplers use beside RCCL: id broadcast, barrier, max / min over ranks,
+"""CPU: the torch-free control plane of the one-process-per-GPU runs (evidence_amd/rendezvous.py) at world sizes 2,
+3 and 8 — the exchange bench.py and the sharded samplers use beside RCCL: id broadcast, barrier, max / min over ranks,
 all-gather of small host buffers — and the socket transport of the sharded log-L."""
 import multiprocessing as mp
 import time
@@ -39,7 +39,7 @@ def _worker(rank, world, address, q):
                wc[:, 0].tolist(), float(wl[3]), used))
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])        # 8: the node size the driver launches; 41 and 10 rows: ragged shards
 def test_rendezvous_collectives_and_socket_transport(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
