@@ -212,6 +212,7 @@ class Watchdog:
         self.hung_line = None                # rank 0: JSON skeleton for the nothing-completed case
         self._stop = threading.Event()
         self._once = threading.Lock()
+        self._asked = None                   # a signal handler's request to report and leave (request_exit)
         self._thread = threading.Thread(target=self._run, daemon=True)
         self._thread.start()
 
@@ -239,8 +240,17 @@ class Watchdog:
         sys.stdout.flush()
         os._exit(code)
 
+    def request_exit(self, why):
+        """For signal handlers: only leave a note — the watchdog thread reports and exits within a tenth of a second.  A
+        handler runs on the main thread, which may itself be inside report_and_exit holding the lock (after a rendezvous
+        error, say): calling report_and_exit from the handler then slept on the very thread that had the line to print, and
+        the launcher's SIGKILL came before the line did."""
+        self._asked = why
+
     def _run(self):
-        while not self._stop.wait(1.0):
+        while not self._stop.wait(0.1):
+            if self._asked is not None:
+                self.report_and_exit(self._asked)
             if time.monotonic() - self.last > self.limit:
                 self.report_and_exit(f"watchdog: no progress for {self.limit:.0f} s")
 
@@ -310,7 +320,7 @@ def fip_extra(with_cpu):
     return res
 
 
-def run_extras(out, model, w, theta, B, with_cpu):
+def run_extras(out, model, w, theta, B, with_cpu, device_index=0):
     """Extras of the N = 1 line (never `value`).  Each one is guarded: an extra that fails is reported under
     `extras_failed` and can never suppress the headline line."""
     def guarded(name, fn):
@@ -459,7 +469,44 @@ def run_extras(out, model, w, theta, B, with_cpu):
         res.update(live_points=32768, deaths_per_iteration=16384,
                    walk="device (rvll_live_step: live set, dead points and the walk resident in HBM)")
         res["host_managed_live_set"] = timed_run(live=False)      # round 2's form: rows through host buffers every iteration
+        res["note"] = ("a THROUGHPUT loop: stopped at max_calls long before convergence (dlogz = 1e-9 never fires), ln Z is 'so far'; "
+                       "converged runs are under nested_sampling_converged")
+        res["walk_form"] = "rounds (step + batch log-L tiles per round, csrc/rvll_rounds.h)" if model.slice_walk_rounds() > 0 else "single kernel"
         out["nested_sampling_end_to_end"] = res
+
+        # Converged evidence runs: dlogz = 0.5 — the reference's UltraNest default, evidence/ultranest/__init__.py:
+        # 333-338 — with the live set resident on the device and host-managed, same seed.  cfg2 (one planet, 6 parameters): the
+        # two forms agree within their errors.  cfg3 (three exchangeable planets, 19 parameters; the priors do not order the
+        # periods, as SURVEY 8d has them): the posterior has 3! equivalent modes and aliases of each, and how many of them a
+        # run's live points hold on to decides its ln Z — runs differ by tens of nats from seed to seed at 8192 live points
+        # (profiles/r04_converged_runs.txt), which is a property of the sampler on this posterior, not of where it runs (the
+        # reference breaks the symmetry with PolyChord's sorted priors: evidence/priors.py:462-467).
+        def converged(wl, mdl, nlive, kbatch, seed):
+            pr, ll = make_ultranest_callbacks(mdl, vectorized=True)
+            got = {}
+            for name, how in (("resident", dict(live=mdl)), ("host_managed", dict(walker=mdl.slice_walk, prior_loglike=mdl.prior_loglike_batch))):
+                t1 = time.perf_counter()
+                ns = run_nested_slice(pr, ll, mdl.ndim, nlive=nlive, kbatch=kbatch, dlogz=0.5, max_calls=2_000_000_000,
+                                      wrapped=wrapped_params(mdl.parnames), seed=seed, **how)
+                el = time.perf_counter() - t1
+                got[name] = {"logz": ns.logz, "logzerr": ns.logzerr, "information": ns.information, "iterations": int(ns.niter),
+                             "calls": int(ns.ncall), "seconds": el, "calls_per_s": ns.ncall / el}
+            d, s = abs(got["resident"]["logz"] - got["host_managed"]["logz"]), float(np.hypot(got["resident"]["logzerr"], got["host_managed"]["logzerr"]))
+            got.update(live_points=nlive, deaths_per_iteration=kbatch, dlogz=0.5, seed=seed, abs_difference=d, combined_sigma=s,
+                       agree_within_3_sigma=bool(d <= 3 * s))
+            return got
+
+        conv = {"cfg3": converged(w, model, 8192, 2048, 1)}
+        try:
+            w2 = make_workload(2)
+            cls, _ = model_class()
+            with cls(w2.fixedpardict, w2.table, w2.parnames, priordict=w2.priordict(), device=device_index) as m2:
+                conv["cfg2"] = converged(w2, m2, 8192, 2048, 1)
+        except Exception as exc:                                  # noqa: BLE001 — an extra never costs the line
+            conv["cfg2_failed"] = f"{type(exc).__name__}: {exc}"
+        conv["note"] = ("cfg3's exchangeable planets make its evidence a matter of how many of the 3! modes (and their aliases) a run holds: "
+                        "seed-to-seed scatter of tens of nats at this size; see profiles/r04_converged_runs.txt")
+        out["nested_sampling_converged"] = conv
 
     def fip():
         out["fip_periodogram"] = fip_extra(with_cpu)
@@ -667,7 +714,7 @@ def run_single(args, w, model, theta, B):
     out, gpu_logl, kern_s = build_line(args, w, model, B, 1, elapsed, "none", 1, model.dev_mark_elapsed_ms() / args.steps)
     out["config"]["prewarm"] = warm
     if not args.no_extras:
-        run_extras(out, model, w, theta, B, not args.no_cpu)
+        run_extras(out, model, w, theta, B, not args.no_cpu, args.device_index)
         cls, _ = model_class()
         try:
             def make(cfg, prec):
@@ -742,7 +789,7 @@ def run_multi(args, w, model, theta, B, rank, world, device_index):
                         "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                         "config": {"workload": WORKLOAD_TEXT[args.config].format(b=B), "cfg": args.config,
                                    "parallelism": f"live-point shards x{world}"}}
-        signal.signal(signal.SIGTERM, lambda *_: wd.report_and_exit("SIGTERM (a peer or the launcher ended the run)"))
+        signal.signal(signal.SIGTERM, lambda *_: wd.request_exit("SIGTERM (a peer or the launcher ended the run)"))
     try:
         _run_multi_body(args, w, model, theta, B, rank, world, device_index, cls, stub, wd, Rendezvous)
     except (RendezvousError, OSError) as exc:

@@ -167,6 +167,18 @@ LIB_PATH = Path(__file__).resolve().parent / "librvll.so"
 _lib = None
 
 
+HW_QUEUES_NOTE = None          # what load() did about GPU_MAX_HW_QUEUES, and whether it can have taken effect (bench.py prints it)
+
+
+def _hip_runtime_loaded():
+    """Is a libamdhip64 already mapped into this process (torch imported first, a profiler's preload, ...)?"""
+    try:
+        with open("/proc/self/maps") as maps:
+            return any("libamdhip64" in line for line in maps)
+    except OSError:
+        return None
+
+
 def load():
     """Load the in-tree HIP library (once) and bind every prototype."""
     global _lib
@@ -181,7 +193,14 @@ def load():
     # starts.  A handle has seven streams; when a copy stream of the streamed host batches shares the kernels' queue, every
     # chunk's kernels wait for a download (csrc/rvll_api.hip, stream_reserve: 3.3 against 2.0 ms at 262144 rows).  Ask for 8
     # unless the user has chosen; results do not depend on it.
+    global HW_QUEUES_NOTE
+    hip_already = _hip_runtime_loaded()
+    chosen = "GPU_MAX_HW_QUEUES" in os.environ
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    HW_QUEUES_NOTE = {"GPU_MAX_HW_QUEUES": os.environ["GPU_MAX_HW_QUEUES"], "set_by": "the caller" if chosen else "evidence_amd (default 8)",
+                      "hip_runtime_loaded_before_librvll": hip_already,
+                      "in_effect": "unknown: the HIP runtime was already up and reads the variable only when it starts" if hip_already and not chosen
+                                   else os.environ["GPU_MAX_HW_QUEUES"]}
     try:
         lib = C.CDLL(str(path))
     except OSError as exc:

@@ -118,12 +118,15 @@ int rvll_runtime_info(char* buf, int32_t buflen)
     int hip_rt = 0, hip_drv = 0;
     (void)hipRuntimeGetVersion(&hip_rt);
     (void)hipDriverGetVersion(&hip_drv);
+    // GPU_MAX_HW_QUEUES as this process's environment has it now (the runtime read it when it started: a caller that set it
+    // later, or loaded another HIP user first, runs on the default 4 whatever this says — evidence_amd/_abi.py records which)
+    const char* q = getenv("GPU_MAX_HW_QUEUES");
     snprintf(buf, (size_t)buflen,
              "{\"hip_runtime_version\": %d, \"hip_driver_version\": %d, \"libamdhip64\": \"%s\", "
-             "\"librccl\": \"%s\", \"rccl_version\": %d, \"librvll\": \"%s\"}",
+             "\"librccl\": \"%s\", \"rccl_version\": %d, \"librvll\": \"%s\", \"gpu_max_hw_queues_env\": \"%s\"}",
              hip_rt, hip_drv, lib_path_of(reinterpret_cast<const void*>(&hipGetDeviceCount)).c_str(),
              g_rccl.lib ? g_rccl_path.c_str() : "not loaded", g_rccl_version,
-             lib_path_of(reinterpret_cast<const void*>(&rvll_runtime_info)).c_str());
+             lib_path_of(reinterpret_cast<const void*>(&rvll_runtime_info)).c_str(), q ? q : "unset (runtime default: 4)");
     return RVLL_OK;
 }
 

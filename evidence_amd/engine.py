@@ -525,7 +525,9 @@ class GpuRVModel:
         import json
         buf = C.create_string_buffer(2048)
         _abi.check(_abi.load().rvll_runtime_info(buf, len(buf)))
-        return json.loads(buf.value.decode())
+        info = json.loads(buf.value.decode())
+        info["hw_queues"] = _abi.HW_QUEUES_NOTE           # set by evidence_amd at load time? in effect?
+        return info
 
     def allgather_logl(self, n_local):
         _abi.check(self._lib.rvll_allgather_logl(self._h, int(n_local)))

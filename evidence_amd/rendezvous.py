@@ -25,12 +25,15 @@ What travels (round 3; ADVICE r2: the first version unpickled whatever arrived, 
     and nothing else: there is no object construction a peer could steer;
   * every frame carries an HMAC-SHA256 over (direction, sender's frame counter, payload) under a key both ends
     derive from a shared secret: RVLL_RDZV_SECRET if set (bench.py's own launcher draws 32 random bytes per run and
-    hands them to its children through the environment), else the run id the launcher exports.  A frame that does
+    hands them to its children through the environment; required for tcp: addresses), else the run id the launcher
+    exports — which under a plain `torch.distributed.run` is the constant "none": then the MAC guards against accidents
+    only and the uid checks below are the barrier.  A frame that does
     not verify closes the connection before a single payload byte is decoded; a replayed or reordered frame does not
     verify either (the counter is part of the MAC);
   * the join is a challenge / response: rank 0 sends a fresh nonce, the peer answers with its rank and
     HMAC(key, nonce | rank), as a fixed-size struct;
-  * on unix sockets rank 0 also drops peers of another uid (SO_PEERCRED) before reading anything.
+  * on unix sockets rank 0 drops peers of another uid (SO_PEERCRED) before reading anything, and the other ranks refuse a
+    hub of another uid (whoever bound the abstract name first).
 """
 import hashlib
 import hmac
@@ -179,8 +182,15 @@ def decode(data):
 def shared_key(address, env=os.environ) -> bytes:
     """Key of the frame MACs: derived from RVLL_RDZV_SECRET (hex or text; bench.py's launcher draws one per run), else
     from the launcher's run id — known to the ranks of one job, not to a stranger who merely finds the socket."""
-    secret = env.get("RVLL_RDZV_SECRET") or "|".join(
-        env.get(k, "") for k in ("TORCHELASTIC_RUN_ID", "MASTER_ADDR", "MASTER_PORT"))
+    secret = env.get("RVLL_RDZV_SECRET")
+    if not secret:
+        # Without a secret the key is made of what the launcher exports — and torchrun's default run id is the literal
+        # "none": such a key is a public constant, good against accidents (two jobs on one port), not against a peer who
+        # wants in.  On a unix socket the uid checks (both ways, below) are then what stands; over tcp nothing would, so a
+        # tcp address requires the secret (ADVICE r3).
+        if address.startswith("tcp:"):
+            raise RendezvousError("a tcp: rendezvous needs RVLL_RDZV_SECRET (the run id alone is not a secret)")
+        secret = "|".join(env.get(k, "") for k in ("TORCHELASTIC_RUN_ID", "MASTER_ADDR", "MASTER_PORT"))
     return hashlib.sha256(b"rvll-rdzv-v2|" + secret.encode() + b"|" + address.encode()).digest()
 
 
@@ -315,6 +325,9 @@ class Rendezvous:
                         raise RendezvousError(f"rank 0 is not listening at {self.address}")
                     time.sleep(0.05)
             s.settimeout(timeout)
+            if self.address.startswith("unix:") and not _same_user(s):      # whoever bound the name first must be this user too
+                s.close()
+                raise RendezvousError(f"the process listening at {self.address} belongs to another user")
             nonce = _recv_exact(s, 32)
             proof = hmac.new(self.key, nonce + struct.pack("!I", rank), hashlib.sha256).digest()
             try:
@@ -328,7 +341,7 @@ class Rendezvous:
         try:
             if self.address.startswith("unix:") and not _same_user(conn):
                 return None
-            conn.settimeout(min(self.timeout, 10.0))
+            conn.settimeout(min(self.timeout, 2.0))          # (a stranger who connects and says nothing holds the joins up this long, no longer)
             nonce = os.urandom(32)
             conn.sendall(nonce)
             magic, peer, proof = _HELLO.unpack(_recv_exact(conn, _HELLO.size))

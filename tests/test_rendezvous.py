@@ -75,10 +75,16 @@ def test_rendezvous_over_tcp_and_single_rank():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), f"tcp://127.0.0.1:{port}"], stdout=subprocess.PIPE, text=True)
+    env = dict(os.environ, RVLL_RDZV_SECRET="s3cret-of-this-test")
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r), f"tcp://127.0.0.1:{port}"], stdout=subprocess.PIPE, text=True, env=env)
              for r in range(2)]
     outs = [p.communicate(timeout=60)[0].strip() for p in procs]
     assert outs == ["3", "3"] and all(p.returncode == 0 for p in procs)
+    # over tcp there is no uid to check: without a secret of its own the rendezvous refuses (the run id is not one — ADVICE r3)
+    from evidence_amd.rendezvous import RendezvousError, shared_key
+    with pytest.raises(RendezvousError, match="RVLL_RDZV_SECRET"):
+        shared_key(f"tcp://127.0.0.1:{port}", env={"TORCHELASTIC_RUN_ID": "none"})
+    assert shared_key("unix:x", env={"TORCHELASTIC_RUN_ID": "none"}) != shared_key("unix:x", env={"RVLL_RDZV_SECRET": "k"})
 
 
 def test_the_control_plane_and_the_bench_launch_path_do_not_import_torch():
