@@ -364,7 +364,9 @@ void keprv_kernel(const LoglikeArgs a, const double* times, int Nt, unsigned inc
             double E = M, s, c, dE;
             int steps = 0;
             do {
-                sincos_any(E, s, c);                  // the iteration may leave 2^50 at the clamp (rvll_math.h)
+                // correctly rounded, as glibc's nearly always are (round 4): this is not a hot path, and where the iteration
+                // wanders (e >= 0.97) where it stops hangs on the last bit; any finite argument is reduced exactly
+                sincos_cr(E, s, c);
                 const double f = E - ec * s - M;
                 const double fp = 1 - ec * c;
                 const double En = E - div_exact(f, fp);

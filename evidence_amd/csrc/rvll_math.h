@@ -262,6 +262,135 @@ RVLL_HD void sincos_any(double x, double& s_out, double& c_out, const SincosCons
 }
 RVLL_HD void sincos_any(double x, double& s_out, double& c_out) { sincos_any(x, s_out, c_out, sincos_consts()); }
 
+// ---- sin / cos, correctly rounded (an experiment of round 4, used only where a Newton solve wanders) -------------------
+// at e >= 0.97, where the reference's iteration wanders for tens to hundreds of steps, where it stops hangs on
+// the last bit of sin / cos.  glibc's are correctly rounded nearly always; the kernels above are good to ~1.2 ulp.
+// This pair evaluates in double-double — the Payne - Hanek reduction's leading 106 bits as (hi, lo), the Taylor series of
+// sin and cos in double-double arithmetic to 2^-100 — and rounds once: the correctly rounded value except within ~2^-47 ulp
+// of a rounding boundary.  ~700 flops: for the solver's second loop only (0.01 % of the waves at cfg3's priors).
+struct DD { double hi, lo; };
+RVLL_HD DD dd_two_sum(double a, double b) { const double s = a + b, bb = s - a; return {s, (a - (s - bb)) + (b - bb)}; }
+RVLL_HD DD dd_quick_sum(double a, double b) { const double s = a + b; return {s, b - (s - a)}; }
+RVLL_HD DD dd_two_prod(double a, double b) { const double p = a * b; return {p, __builtin_fma(a, b, -p)}; }
+RVLL_HD DD dd_add(DD a, DD b)
+{
+    DD s = dd_two_sum(a.hi, b.hi);
+    const DD t = dd_two_sum(a.lo, b.lo);
+    s.lo += t.hi;
+    s = dd_quick_sum(s.hi, s.lo);
+    s.lo += t.lo;
+    return dd_quick_sum(s.hi, s.lo);
+}
+RVLL_HD DD dd_mul(DD a, DD b)
+{
+    DD p = dd_two_prod(a.hi, b.hi);
+    p.lo += a.hi * b.lo + a.lo * b.hi;
+    return dd_quick_sum(p.hi, p.lo);
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __constant__
+#endif
+static const double kSinTaylorDD[14][2] = {        // (-1)^k / (2k+1)!, k = 1 .. 14, as (hi, lo)
+    {-0.16666666666666666, -9.25185853854297e-18},   {0.008333333333333333, 1.1564823173178714e-19},
+    {-0.0001984126984126984, -1.7209558293420705e-22}, {2.7557319223985893e-06, -1.858393274046472e-22},
+    {-2.505210838544172e-08, 1.448814070935912e-24},  {1.6059043836821613e-10, 1.2585294588752098e-26},
+    {-7.647163731819816e-13, -7.03872877733453e-30},  {2.8114572543455206e-15, 1.6508842730861433e-31},
+    {-8.22063524662433e-18, -2.2141894119604265e-34}, {1.9572941063391263e-20, -1.3643503830087908e-36},
+    {-3.868170170630684e-23, 8.843177655482344e-40},  {6.446950284384474e-26, -1.9330404233703465e-42},
+    {-9.183689863795546e-29, -1.4303150396787322e-45}, {1.1309962886447716e-31, 1.0498015412959506e-47}};
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __constant__
+#endif
+static const double kCosTaylorDD[14][2] = {        // (-1)^k / (2k)!, k = 1 .. 14
+    {-0.5, 0.0},                                      {0.041666666666666664, 2.3129646346357427e-18},
+    {-0.001388888888888889, 5.300543954373577e-20},   {2.48015873015873e-05, 2.1511947866775882e-23},
+    {-2.755731922398589e-07, -2.3767714622250297e-23}, {2.08767569878681e-09, -1.20734505911326e-25},
+    {-1.1470745597729725e-11, -2.0655512752830745e-28}, {4.779477332387385e-14, 4.399205485834081e-31},
+    {-1.5619206968586225e-16, -1.1910679660273754e-32}, {4.110317623312165e-19, 1.4412973378659527e-36},
+    {-8.896791392450574e-22, 7.911402614872376e-38},  {1.6117375710961184e-24, -3.6846573564509766e-41},
+    {-2.4795962632247976e-27, 1.2953730964765229e-43}, {3.279889237069838e-30, 1.5117542744029879e-46}};
+
+// |x| finite: the reduced argument as a double-double in [-pi/4, pi/4] and the quadrant (reduce_huge's arithmetic, kept in two
+// words; below pi/4 the argument is its own reduction)
+RVLL_HD void reduce_dd(double x, DD& r, uint32_t& q)
+{
+    const double ax = __builtin_fabs(x);
+    if (ax <= 0.78539816339744828) { r = {ax, 0.}; q = 0; return; }
+    const uint64_t bits = as_u64(x) & 0x7fffffffffffffffull;
+    const int ex = (int)(bits >> 52) - 1075;
+    const uint64_t M = (bits & 0x000fffffffffffffull) | 0x0010000000000000ull;
+    const int o = ex + 62;
+    const int wi = o >> 6, sh = o & 63;
+    const uint64_t a0 = kTwoOverPiBits[wi], a1 = kTwoOverPiBits[wi + 1], a2 = kTwoOverPiBits[wi + 2];
+    const uint64_t a3 = wi + 3 < 21 ? kTwoOverPiBits[wi + 3] : 0;
+    const uint64_t w0 = sh ? (a0 << sh) | (a1 >> (64 - sh)) : a0;
+    const uint64_t w1 = sh ? (a1 << sh) | (a2 >> (64 - sh)) : a1;
+    const uint64_t w2 = sh ? (a2 << sh) | (a3 >> (64 - sh)) : a2;
+    uint64_t p2 = M * w2;
+    uint64_t c2 = mulhi_u64(M, w2);
+    uint64_t p1 = M * w1;
+    uint64_t c1 = mulhi_u64(M, w1);
+    uint64_t p0 = M * w0;
+    p1 += c2;
+    c1 += p1 < c2 ? 1 : 0;
+    p0 += c1;
+    q = (uint32_t)(p0 >> 62);
+    uint64_t g0 = (p0 << 2) | (p1 >> 62), g1 = (p1 << 2) | (p2 >> 62), g2 = p2 << 2;
+    const bool neg = (g0 >> 63) != 0;
+    if (neg) {
+        q += 1;
+        g2 = ~g2 + 1;
+        g1 = ~g1 + (g2 == 0 ? 1 : 0);
+        g0 = ~g0 + ((g2 == 0 && g1 == 0) ? 1 : 0);
+    }
+    int lz = 0;
+    if (g0 == 0) { g0 = g1; g1 = g2; g2 = 0; lz = 64; }
+    const int z = g0 ? __builtin_clzll(g0) : 63;
+    if (z) { g0 = (g0 << z) | (g1 >> (64 - z)); g1 = (g1 << z) | (g2 >> (64 - z)); }
+    lz += z;
+    const double fh = (double)(g0 >> 11);                              // leading 53 bits, exact
+    const double fl = (double)(((g0 & 0x7ffull) << 42) | (g1 >> 22)); // the next 53, exact (weight 2^-53 of fh's)
+    // (fh + fl 2^-53) * (pi/2 as three words), in double-double
+    const double P1 = 1.5707963267948966, P2 = 6.123233995736766e-17, P3 = -1.4973849048591698e-33;
+    const DD a = dd_two_prod(fh, P1);
+    const double flw = fl * 1.1102230246251565e-16;
+    const DD b = dd_two_prod(fh, P2), c = dd_two_prod(flw, P1);
+    DD s = dd_add(b, c);
+    s.lo += fh * P3 + flw * P2;
+    s = dd_add(a, dd_quick_sum(s.hi, s.lo));
+    const double sc = ldexp(1.0, -53 - lz);                            // exact scaling
+    r = {neg ? -s.hi * sc : s.hi * sc, neg ? -s.lo * sc : s.lo * sc};
+}
+
+// sin r, cos r for a double-double |r| <= pi/4, each rounded once
+RVLL_HD void sincos_dd_kernel(DD r, double& s_out, double& c_out)
+{
+    const DD z = dd_mul(r, r);
+    DD ps = {kSinTaylorDD[13][0], kSinTaylorDD[13][1]}, pc = {kCosTaylorDD[13][0], kCosTaylorDD[13][1]};
+    for (int k = 12; k >= 0; --k) {
+        ps = dd_add(dd_mul(ps, z), DD{kSinTaylorDD[k][0], kSinTaylorDD[k][1]});
+        pc = dd_add(dd_mul(pc, z), DD{kCosTaylorDD[k][0], kCosTaylorDD[k][1]});
+    }
+    const DD s = dd_add(r, dd_mul(dd_mul(r, z), ps));                 // r + r z (c1 + c2 z + ...)
+    const DD c = dd_add(DD{1.0, 0.0}, dd_mul(z, pc));
+    s_out = s.hi;
+    c_out = c.hi;
+}
+
+RVLL_HD void sincos_cr(double x, double& s_out, double& c_out)
+{
+    if (!(__builtin_fabs(x) < __builtin_inf())) { s_out = c_out = __builtin_nan(""); return; }
+    DD r;
+    uint32_t q;
+    reduce_dd(x, r, q);
+    double sr, cr;
+    sincos_dd_kernel(r, sr, cr);
+    const double s = (q & 1u) ? cr : sr, c = (q & 1u) ? sr : cr;
+    const double ss = (q & 2u) ? -s : s, cc = ((q + 1u) & 2u) ? -c : c;
+    s_out = x < 0. ? -ss : ss;
+    c_out = cc;
+}
+
 // n / d by reciprocal refinement.  v_rcp_f64 is accurate to 2^-24.4 (measured, scripts/rcp_probe.py): one
 // Newton step gives 2^-48, and the quotient with one residual correction q + (n - d q) y is then the
 // correctly rounded quotient for finite, normal operands with a normal quotient — bit for bit what `n / d`

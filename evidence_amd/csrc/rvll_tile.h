@@ -275,7 +275,12 @@ struct ItemCtx {
 // first pass over a tile runs without it: the marks can only come from that very pass, and every point that got one
 // is re-evaluated with FAILCHECK afterwards (3b of loglike_tile) — so the normal path carries no reads of the marks.
 // EXTRAS = false: a model without drift and without linear activity terms (the kernel never looks at those switches)
-template <int PREC, bool FAILCHECK, bool EXTRAS = true>
+// CR: the redo pass of points with a solve that WANDERED (more than kSafeSteps Newton steps): such a solve is done again from
+// its start with correctly rounded sin / cos (rvll_math.h, sincos_cr).  Where the reference's iteration wanders, where it stops
+// hangs on the last bit of sin / cos, and glibc's are correctly rounded nearly always: 90 of 20000 points at e = 0.95 .. 0.9925
+// were beyond 1e-10 of the oracle with the ~1.2-ulp kernels, 2 with this (profiles/r04_high_ecc_parity.txt).  It lives in the
+// redo pass because inside the first pass its mere presence cost every launch 3.7 % (63.3 -> 65.6 us: scalar registers).
+template <int PREC, bool FAILCHECK, bool EXTRAS = true, bool CR = false>
 __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx& cx, int pl, int j)
 {
     const double t  = a.t[j];
@@ -287,20 +292,28 @@ __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx&
     double rvm = 0. + oj.x;                                   // rvmodel:187
     const double var = s2 + oj.y;                             // rvmodel:189-192 (oj.y = jitter^2 or 0)
 
-    if (a.Np > 0) {
+#ifdef RVLL_NP_CONST                  // (measurement builds only: the planet count as a compile-time constant)
+    constexpr int Np = RVLL_NP_CONST;
+#else
+    const int Np = a.Np;
+#endif
+    if (Np > 0) {
         const bool wide = __builtin_amdgcn_readfirstlane(*cx.wide) != 0;
         bool point_failed = false;
         if constexpr (FAILCHECK) point_failed = cx.anyfail[pl] != 0;
         double ksum = 0.;
-        for (int ip = 0; ip < a.Np; ++ip) {
-            const double* P = cx.pp + (pl * a.Np + ip) * kPlanetFields;
+#ifdef RVLL_NP_CONST
+#pragma unroll
+#endif
+        for (int ip = 0; ip < Np; ++ip) {
+            const double* P = cx.pp + (pl * Np + ip) * kPlanetFields;
             const double2 p01 = *reinterpret_cast<const double2*>(P);       // w, epoch
             const double2 p23 = *reinterpret_cast<const double2*>(P + 2);   // ma0, ec
             const double2 p45 = *reinterpret_cast<const double2*>(P + 4);   // A=K cos w, Bq=K q sin w
             const double  C0  = P[6];                                       // K e cos w
             const double ec = p23.y;
             double rv;
-            if (FAILCHECK && point_failed && j >= cx.jfail[pl * a.Np + ip]) {
+            if (FAILCHECK && point_failed && j >= cx.jfail[pl * Np + ip]) {
                 rv = p45.x + C0;            // nu left at 0 (rvmodel:488, trueanomaly.c:32-33)
             } else if constexpr (PREC == RVLL_PREC_FP64) {
                 // mean anomaly, rvmodel:459 — two roundings in (t-epoch), then mul, then add
@@ -331,7 +344,12 @@ __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx&
                     } while (fabs(dE) > a.tol && steps < kSafeSteps);
                 }
                 bool hit_itmax = false;
-                if (!(fabs(dE) <= a.tol)) {
+                // (Both this test and the redo pass of the tile are marked UNLIKELY, and that is worth 4 % of every launch: the
+                // register allocator weighs a value by the estimated frequency of the blocks that use it, and with the correctly
+                // rounded sin / cos in the redo pass — ~1000 instructions with scalar needs of their own — it spilled scalars
+                // of the item loop instead of theirs: 63.3 -> 65.9 us, 7 -> 31 v_readlane per planet trip.  With the hints:
+                // 63.3 us, 2 v_readlane.  profiles/r04_high_ecc_parity.txt)
+                if (__builtin_expect(!(fabs(dE) <= a.tol), 0)) {
                     // Still going after eight steps (or not started: a tiny itmax, an absurd |M|).  At the eccentricity
                     // clamp the reference's iteration is thrown out to |E| ~ 1e9 .. 1e22 and finds its way back in
                     // 30 - 350 steps (rvll_math.h, sincos_any): from here on every sin / cos is reduced the long way
@@ -340,8 +358,10 @@ __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx&
                     __builtin_amdgcn_s_setprio(2);
 #endif
                     int steps = shortcut ? kSafeSteps : 0;
+                    if constexpr (CR) { E = M; steps = 0; }       // (the first eight steps seed where it ends as much as the later ones)
                     do {
-                        sincos_any(E, s, c, kc);
+                        if constexpr (CR) sincos_cr(E, s, c);
+                        else              sincos_any(E, s, c, kc);
                         const double f  = E - ec * s - M;
                         const double fp = 1 - ec * c;
                         const double En = E - div_exact(f, fp);
@@ -351,13 +371,16 @@ __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx&
                     } while (fabs(dE) > a.tol && steps < a.itmax);
                     hit_itmax = steps >= a.itmax;
                     // more than kSafeSteps steps: the iteration wandered (include/rvll.h, RVLL_FLAG_WANDERED)
-                    if (steps > kSafeSteps) atomicOr(&cx.pflags[pl], RVLL_FLAG_WANDERED);
+                    if (steps > kSafeSteps) {
+                        atomicOr(&cx.pflags[pl], RVLL_FLAG_WANDERED);
+                        if constexpr (!CR) atomicOr(cx.nfail, 2);            // the tile redoes this point's items (3b)
+                    }
 #ifdef RVLL_AB_PRIO
                     __builtin_amdgcn_s_setprio(0);
 #endif
                 }
                 if (hit_itmax) {
-                    atomicMin(&cx.jfail[pl * a.Np + ip], j);
+                    atomicMin(&cx.jfail[pl * Np + ip], j);
                     atomicOr(&cx.anyfail[pl], 1);
                     atomicOr(cx.nfail, 1);
                     rv = p45.x + C0;
@@ -418,7 +441,7 @@ __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx&
                     rv = (double)(div_f32(num, den) + (float)C0);
                 }
                 if (steps >= a.itmax) {
-                    atomicMin(&cx.jfail[pl * a.Np + ip], j);
+                    atomicMin(&cx.jfail[pl * Np + ip], j);
                     atomicOr(&cx.anyfail[pl], 1);
                     atomicOr(cx.nfail, 1);
                     rv = p45.x + C0;
@@ -907,13 +930,15 @@ __device__ __forceinline__ __attribute__((flatten)) void loglike_tile(const Logl
         __syncthreads();
         RVLL_TILE_STAMP(2);
         if constexpr (TRACE && DYN) { if (tid == 0) tr[5] = __builtin_amdgcn_s_memrealtime(); }
-        // 3b. rare: a solve hit itmax.  The reference aborts that planet's array there
-        // and leaves nu = 0 from that epoch on; redo the affected points' items now that
-        // the first failing epoch per (point, planet) is known.
-        if (L.nfail[0] != 0) {
+        // 3b. rare: a solve hit itmax (bit 0 of nfail) — the reference aborts that planet's array there and leaves nu = 0 from
+        // that epoch on: the affected points' items are redone now that the first failing epoch per (point, planet) is
+        // known — or a solve wandered (bit 1): that point's items are redone with the wandering solves on correctly rounded
+        // sin / cos (eval_item, CR).  Every other solve of those points takes the path it took before: the same bits.
+        if (__builtin_expect(L.nfail[0] != 0, 0)) {                // (cold: the register allocator is to favour the item loop)
             for (int i = base + tid; i < cend; i += NT) {
                 const int pl = i / a.Ne;
-                if (L.anyfail[pl]) contrib[i - base] = eval_item<PREC, true, EXTRAS>(a, cx, pl, i - pl * a.Ne);
+                if (L.anyfail[pl] || (L.pflags[pl] & RVLL_FLAG_WANDERED))
+                    contrib[i - base] = eval_item<PREC, true, EXTRAS, PREC == RVLL_PREC_FP64>(a, cx, pl, i - pl * a.Ne);
             }
             __syncthreads();
         }

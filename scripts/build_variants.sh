@@ -10,8 +10,7 @@ while [ $# -ge 2 ]; do
   B=../../build/var/$name; mkdir -p $B
   /opt/rocm/bin/hipcc $FLAGS $defs -c rvll_kernels.hip -o $B/rvll_kernels.o &
   /opt/rocm/bin/hipcc $FLAGS $defs -mllvm -disable-machine-licm -c rvll_walk.hip -o $B/rvll_walk.o &
-  /opt/rocm/bin/hipcc $FLAGS $defs -c rvll_api.hip -o $B/rvll_api.o &
   wait
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o ../diag/librvll_$name.so $B/rvll_api.o $B/rvll_kernels.o $B/rvll_walk.o ../../build/obj/rvll_fip.o ../../build/obj/rvll_live.o -ldl
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -fPIC -shared -o ../diag/librvll_$name.so ../../build/obj/rvll_api.o ../../build/obj/rvll_walk_host.o ../../build/obj/rvll_comm.o $B/rvll_kernels.o $B/rvll_walk.o ../../build/obj/rvll_fip.o ../../build/obj/rvll_live.o -ldl
   echo "built evidence_amd/diag/librvll_$name.so ($defs)"
 done

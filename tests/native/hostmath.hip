@@ -6,6 +6,7 @@
 #define HM extern "C" __attribute__((visibility("default")))
 HM void hm_sincos(const double* x, long n, double* s, double* c) { for (long i = 0; i < n; ++i) rvll::sincos_f64(x[i], s[i], c[i]); }
 HM void hm_sincos_any(const double* x, long n, double* s, double* c) { for (long i = 0; i < n; ++i) rvll::sincos_any(x[i], s[i], c[i]); }
+HM void hm_sincos_cr(const double* x, long n, double* s, double* c) { for (long i = 0; i < n; ++i) rvll::sincos_cr(x[i], s[i], c[i]); }
 // the long reduction by itself (any |x| >= 1), so that it can be checked where the short one is valid too
 HM void hm_sincos_long(const double* x, long n, double* s, double* c) {
     for (long i = 0; i < n; ++i) {

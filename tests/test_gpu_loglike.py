@@ -286,9 +286,10 @@ def test_unusual_model_shapes_match_oracle(gpu_required, n_epochs, nplanets, nin
 def test_high_eccentricity_parity_is_the_references_own_conditioning(gpu_required):
     """Where Newton from E = M is least forgiving (one planet at e = 0.95 .. 0.9925; at the 0.99 clamp the iteration is
     thrown out to |E| ~ 1e9 .. 1e22 and finds its way back): the device follows the reference's path — every
-    sin / cos out there is reduced exactly (rvll_math.h, sincos_any) — to within what the reference's own value is worth:
-    the oracle with its sin / cos nudged by one unit in the last place moves by up to ~1e-9 on 1-3 % of such points, and
-    the device is no further from the oracle than that.  Points none of whose solves wanders (<= 12 steps) meet 1e-10."""
+    sin / cos out there is reduced exactly and, for a solve that wanders, rounded correctly (rvll_math.h, sincos_cr) — far
+    closer than the reference's own value is worth: the oracle with its sin / cos nudged by one unit in the last place moves
+    by up to ~1e-9 on 1-3 % of such points; the device is beyond 1e-10 on ~0.01 %.  Points none of whose solves wanders
+    (<= 12 steps) meet 1e-10."""
     from oracle.oracle import OracleModel
     case = golden.high_ecc_case()
     names = case.parnames
@@ -305,8 +306,12 @@ def test_high_eccentricity_parity_is_the_references_own_conditioning(gpu_require
     ref, rflags = om.loglike(theta, nthreads=8, return_flags=True)
     cond = np.maximum(om.conditioning(theta, nthreads=8, eps=-2.0 ** -53), om.conditioning(theta, nthreads=8, eps=2.0 ** -52))
     err = golden.rel_err(got, ref)
-    assert err.max() <= 5e-9, float(err.max())                       # (before the long reduction: up to 0.18)
-    assert (err > TOL).sum() <= max(10, 2 * (cond > TOL).sum())       # no more often off than the reference from itself
+    # Round 4: a solve that wanders is done again, from its start, with CORRECTLY ROUNDED sin / cos (rvll_math.h, sincos_cr; the
+    # redo pass of the tile) — what glibc's are nearly always.  Measured on 20000 such points (profiles/r04_high_ecc_parity.txt):
+    # beyond 1e-10: 90 -> 2, the largest 6.6e-10 -> 3.3e-10.  (Round 3's bounds here: 5e-9, and "no more often than twice the
+    # reference from itself one ulp of libm away".)
+    assert err.max() <= 1e-9, float(err.max())                       # (this sample: one point, 7.0e-10; round 3: 5e-9 allowed)
+    assert (err > TOL).sum() <= max(2, (cond > TOL).sum() // 10)      # an order of magnitude rarer than the reference from itself
     # wherever no solve of the point wanders (the oracle's own step counts: <= 12 everywhere), the plain bar holds
     worst = np.argsort(-err)[:200]
     for i in worst:
