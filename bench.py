@@ -445,6 +445,7 @@ def run_extras(out, model, w, theta, B, with_cpu, device_index=0):
 
             class Live:                   # the same for the resident live set: time inside rvll_live_step
                 live_init, live_get, live_dead, live_dead_count = model.live_init, model.live_get, model.live_dead, model.live_dead_count
+                live_sort = model.live_sort
 
                 @staticmethod
                 def live_step(*a, **k):

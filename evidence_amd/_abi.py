@@ -102,6 +102,7 @@ PROTOTYPES = {
     "rvll_live_init": (C.c_int, [Handle, _dp, C.c_int64, _dp]),
     "rvll_live_step": (C.c_int, [Handle, _ip, C.c_int64, _ip, C.c_double, _dp, _ip, C.c_int32, C.c_int32, C.c_uint64,
                                  C.c_int64, C.POINTER(C.c_int64), _dp, _dp]),
+    "rvll_live_sort": (C.c_int, [Handle, C.c_int64, _dp, _dp, _dp]),
     "rvll_live_get": (C.c_int, [Handle, _dp, _dp, _dp]),
     "rvll_live_dead": (C.c_int, [Handle, C.POINTER(C.c_int64), _dp, _dp]),
     "rvll_scalar_server": (C.c_int, [Handle, C.c_int32]),
@@ -128,6 +129,7 @@ PROTOTYPES = {
     "rvll_slice_walk_evaluated": (C.c_int, [Handle, C.POINTER(C.c_int64)]),
     "rvll_slice_walk_phases": (C.c_int, [Handle, C.POINTER(C.c_uint64)]),
     "rvll_slice_walk_rounds": (C.c_int, [Handle, C.POINTER(C.c_int32)]),
+    "rvll_set_wander_exact": (C.c_int, [Handle, C.c_int32]),
     "rvll_comm_unique_id": (C.c_int, [C.POINTER(C.c_ubyte)]),
     "rvll_comm_init": (C.c_int, [Handle, C.POINTER(C.c_ubyte), C.c_int32, C.c_int32]),
     "rvll_comm_add_lanes": (C.c_int, [Handle, C.c_int32, _ip]),

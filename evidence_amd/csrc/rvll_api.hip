@@ -256,6 +256,7 @@ int build_args(rvll_handle* h, const double* d_theta, double* d_logL, int32_t* d
     a.has_jitter = h->L.has_jitter; a.has_drift = h->L.has_drift;
     a.tref_from_data = h->L.tref_from_data;
     a.tol = h->L.tol; a.itmax = h->L.itmax; a.precision = h->L.precision;
+    a.cr_redo = h->wander_exact;
     a.PB = choose_points_per_block(h, B);
     a.CH = std::min(h->chunk_items, std::max(rvll::kThreads, a.PB * h->Ne));
     a.CH = (a.CH + 1) & ~1;
@@ -419,6 +420,7 @@ int rvll_create(const rvll_layout* layout, const double* time, const double* vra
     h->lanes[0] = h->compute;
     for (int l = 1; l < kMaxLanes; ++l) CREATE_TRY(hipStreamCreateWithFlags(&h->lanes[l], hipStreamNonBlocking));
     if (const char* e = getenv("RVLL_LANES")) h->nlanes_dev = std::max(1, std::min(kMaxLanes, atoi(e)));
+    if (const char* e = getenv("RVLL_WANDER_EXACT")) h->wander_exact = atoi(e) != 0;
     CREATE_TRY(hipHostMalloc(&h->pin_in, rvll_handle::kPinBytes, hipHostMallocMapped));
     CREATE_TRY(hipHostMalloc(&h->pin_out, rvll_handle::kPinBytes, hipHostMallocMapped));
     CREATE_TRY(hipHostGetDevicePointer(&h->pin_in_dev, h->pin_in, 0));
@@ -498,12 +500,13 @@ int rvll_destroy(rvll_handle* h)
     for (int l = 0; l < kMaxLanes; ++l) { dev_free(h->d_logL2[l]); dev_free(h->d_flags2[l]); dev_free(h->d_gather2[l]); }
     dev_free(h->d_gather_theta); dev_free(h->d_gather_host_in); dev_free(h->d_gather_host_out);
     dev_free(h->d_live_u); dev_free(h->d_live_theta); dev_free(h->d_live_logl); dev_free(h->d_live_idx); dev_free(h->d_live_mom);
+    dev_free(h->d_sort_keys); dev_free(h->d_sort_rows); dev_free(h->d_sort_temp);
     dev_free(h->d_dead_theta); dev_free(h->d_dead_logl);
     if (h->pin_in) (void)hipHostFree(h->pin_in);
     if (h->pin_out) (void)hipHostFree(h->pin_out);
     if (h->pin_defer) (void)hipHostFree(h->pin_defer);
     stream_free(h);
-    dev_free(h->d_walk_steps); dev_free(h->d_walk_wid); dev_free(h->d_walk_start); dev_free(h->d_walk_cost); dev_free(h->d_walk_order);
+    dev_free(h->d_walk_steps); dev_free(h->d_walk_wid); dev_free(h->d_walk_start); dev_free(h->d_walk_cost); dev_free(h->d_walk_order); dev_free(h->d_walk_wflag);
     dev_free(h->d_rounds); dev_free(h->d_walk_dirs);
     if (h->pin_rounds) (void)hipHostFree(h->pin_rounds);
     if (h->ev_rounds) (void)hipEventDestroy(h->ev_rounds);
@@ -1562,6 +1565,13 @@ int rvll_prior_loglike_batch(rvll_handle* h, const double* cube, int64_t B,
     return rvll_dev_download(h, B, theta_out, logL, flags);
 }
 
+
+int rvll_set_wander_exact(rvll_handle* h, int32_t on)
+{
+    if (!h) return fail(RVLL_E_INVALID, "null handle");
+    h->wander_exact = on != 0;
+    return RVLL_OK;
+}
 
 int rvll_set_slim_table_range(rvll_handle* h, double umax)
 {

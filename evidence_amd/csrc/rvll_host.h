@@ -140,6 +140,8 @@ struct rvll_handle {
     unsigned long long* d_walk_ncalls = nullptr;
     int32_t *d_walk_steps = nullptr, *d_walk_wid = nullptr, *d_walk_start = nullptr;   // [walk_cap] each
     int32_t *d_walk_cost = nullptr, *d_walk_order = nullptr;                            // [walk_cap] each (two-part walks)
+    int32_t* d_walk_wflag = nullptr;            // [walk_cap] 1: the walker's last accepted candidate had a wandering solve (walk_core puts its log-L right)
+    int wander_exact = 1;                       // wandering solves are redone with correctly rounded sin / cos (rvll_set_wander_exact; RVLL_WANDER_EXACT)
     int walk_spec = 4;                          // candidates a walker may evaluate ahead per iteration (rvll_set_walk_speculation)
     // the walk as rounds of launches (rvll_rounds.hip; walk_rounds in rvll_walk_host.hip): one arena with every group's walker
     // state, candidate slots and counters; a progress word per group in mapped pinned memory
@@ -162,6 +164,13 @@ struct rvll_handle {
     double *d_live_u = nullptr, *d_live_theta = nullptr, *d_live_logl = nullptr;
     int32_t* d_live_idx = nullptr;              // [2 * live_cap] order, then start rows, of the current step
     double *d_live_mom = nullptr;               // scratch, mean, covariance of the whitening
+    // the order on the device (rvll_live_sort): keys in / out, rows in (the order itself lands in d_live_idx), rocPRIM's scratch
+    unsigned long long* d_sort_keys = nullptr;  // [2 * live_cap]
+    int32_t* d_sort_rows = nullptr;             // [live_cap]
+    void* d_sort_temp = nullptr;
+    size_t sort_temp_bytes = 0;
+    long long sorted_kdead = -1;                // kdead of the rvll_live_sort whose order d_live_idx holds (-1: none, or used up)
+    double sorted_lstar = 0.;
     long long dead_n = 0, dead_cap = 0;
     double *d_dead_theta = nullptr, *d_dead_logl = nullptr;
 

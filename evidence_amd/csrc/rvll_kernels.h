@@ -40,6 +40,7 @@ struct LoglikeArgs {
     double tol;
     int    itmax;
     int    precision;        // RVLL_PREC_*
+    int    cr_redo;          // 1: a Kepler solve that wanders is redone with correctly rounded sin / cos (rvll_tile.h, eval_item<.., CR>)
     // geometry
     int    PB;               // live points per workgroup
     int    CH;               // contribution slots in LDS (items per chunk)
@@ -107,6 +108,8 @@ struct WalkArgs {
     const int32_t* order;         // [K] or null: the order in which rows are handed to walker slots (default: by index)
     int32_t* cost;                // [K] or null, out: candidates every row used in this launch
     int rows_per_wg;              // the "rows" form (launch_slice_walk_rows): rows every workgroup owns for the whole launch
+    int32_t* wflag;               // [K] or null, out: 1 where the walker's LAST accepted candidate carried RVLL_FLAG_WANDERED (its log-L is
+                                  // then put right by the host with the exact redo, which the walk's tiles leave out: walk_core)
 };
 constexpr int kWalkCholLds = 48;   // the walk stages a whitening factor of up to 48 x 48 (18 KB) in LDS
 size_t walk_lds_bytes(const LoglikeArgs& a);
@@ -150,6 +153,7 @@ struct RoundsArgs {
     double* tmin;              // [K] bracket of the move in progress
     double* tmax;              // [K]
     int32_t* step;             // [K] moves completed (out: steps_done — < nsteps: stopped at a candidate the slim stage deferred)
+    int32_t* wflag;            // [K] out: 1 where the walker's last accepted candidate carried RVLL_FLAG_WANDERED (as WalkArgs::wflag)
     int32_t* ws;               // [K, 4] state (0 starts a move, 1 in a move, 3 deferred, 4 finished), round, first slot, slots
     long long K;
     unsigned long long wid0;   // random-number counter index of the group's first walker (walker_base + its row)
@@ -218,6 +222,12 @@ hipError_t launch_scatter_rows(const double* src, const int32_t* idx, long long 
 size_t moments_scratch_doubles(int D);
 hipError_t launch_moments(const double* u, const int32_t* idx, long long n, int D, double* scratch, double* mean, double* cov,
                           hipStream_t st);
+// the live points' order on the device: stable ascending order of logl[0..n) (rocPRIM radix sort on order-preserving keys; ties
+// by row, as numpy's stable argsort has them); out[i] = order[offset + rank[i]]
+size_t sort_temp_bytes(long long n);
+hipError_t launch_sort_logl(const double* logl, long long n, unsigned long long* keys_in, unsigned long long* keys_out, int32_t* rows_in,
+                            int32_t* order_out, void* temp, size_t temp_bytes, hipStream_t st);
+hipError_t launch_compose_index(const int32_t* order, long long offset, const int32_t* rank, long long n, int32_t* out, hipStream_t st);
 
 // ---- scalar-call server: a one-workgroup persistent kernel that answers single-point log-L requests through a
 // block of host-coherent pinned memory, so a scalar callback costs a PCIe round trip instead of a kernel launch

@@ -553,7 +553,7 @@ hipError_t launch_rounds(const RoundsArgs* step, int r_step, const LoglikeArgs* 
         g = *step;
         if (g.W < 1 || g.W > kWave || g.D < 1 || g.spec_max < 1 || g.C < g.K || g.c_free > g.C || g.c_free < 1 || r_step < 0 ||
             g.nsteps >= (1 << 18) || g.max_rounds < 1 || g.max_rounds > 4096 || (long long)g.K * g.spec_max >= (1LL << 31) ||
-            !g.priors || !g.light_dims || (g.n_heavy > 0 && !g.heavy_dims) || g.n_heavy > g.D || !g.theta_c[0] || !g.theta_c[1] || !g.wdef ||
+            !g.priors || !g.light_dims || (g.n_heavy > 0 && !g.heavy_dims) || g.n_heavy > g.D || !g.theta_c[0] || !g.theta_c[1] || !g.wdef || !g.wflag ||
             !g.dirs || !g.dirnext || step_lds_bytes(g.W, g.D, g.spec_max) > lds)
             return hipErrorInvalidValue;
         n_step = (int)((g.K + g.W - 1) / g.W);
@@ -596,7 +596,7 @@ static bool rounds_step_ok(const RoundsArgs& g, int r)
 {
     return !(g.W < 1 || g.W > kWave || g.D < 1 || g.spec_max < 1 || g.C < g.K || g.c_free > g.C || g.c_free < 1 || r < 0 ||
              g.nsteps >= (1 << 18) || g.max_rounds < 1 || g.max_rounds > 4096 || (long long)g.K * g.spec_max >= (1LL << 31) ||
-             !g.priors || !g.light_dims || (g.n_heavy > 0 && !g.heavy_dims) || g.n_heavy > g.D || !g.theta_c[0] || !g.theta_c[1] || !g.wdef || !g.dirs || !g.dirnext);
+             !g.priors || !g.light_dims || (g.n_heavy > 0 && !g.heavy_dims) || g.n_heavy > g.D || !g.theta_c[0] || !g.theta_c[1] || !g.wdef || !g.wflag || !g.dirs || !g.dirnext);
 }
 
 hipError_t launch_rounds_step(const RoundsArgs& g, int round, hipStream_t stream)

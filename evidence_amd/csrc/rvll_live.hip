@@ -7,6 +7,8 @@
 // through PCIe (a fifth of the end-to-end time): these kernels keep all of it in HBM.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstring>
+#include <rocprim/rocprim.hpp>
 #include "rvll_kernels.h"
 
 namespace rvll {
@@ -78,21 +80,81 @@ void moments_fold_kernel(const double* part, int width, double scale, double* ou
     }
 }
 
-// partial sums of the centred products (u_j - m_j)(u_l - m_l): thread p one (j, l) pair, rows as above
+// partial sums of the centred products (u_j - m_j)(u_l - m_l): thread p one (j, l) pair, rows as above — staged through LDS
+// kCovRows at a time (read from HBM row by row, every (j, l) pair waited ~2 us for each of its block's rows: 51 us a call at
+// 16384 rows; the sums are the same terms in the same order)
+constexpr int kCovRows = 32;
 __global__ __launch_bounds__(kThreads)
 void moments_cov_kernel(const double* u, const int32_t* idx, long long n, int D, const double* mean,
                         double* part /*[kMomBlocks][D*D]*/)
 {
-    for (int p = threadIdx.x; p < D * D; p += kThreads) {
-        const int j = p / D, l = p - j * D;
-        const double mj = mean[j], ml = mean[l];
-        double s = 0.;
-        for (long long i = blockIdx.x; i < n; i += kMomBlocks) {
-            const double* row = u + (long long)idx[i] * D;
-            s += (row[j] - mj) * (row[l] - ml);
+    extern __shared__ double rows[];                         // [kCovRows][D], centred
+    double* ms = rows + (size_t)kCovRows * D;                // [D]
+    for (int d = threadIdx.x; d < D; d += kThreads) ms[d] = mean[d];
+    constexpr int kPairs = 8;                                // (j, l) pairs a thread may hold: D * D <= kPairs * kThreads
+    double s[kPairs];
+#pragma unroll
+    for (int q = 0; q < kPairs; ++q) s[q] = 0.;
+    const bool in_regs = (long long)D * D <= (long long)kPairs * kThreads;
+    if (!in_regs) for (int p = threadIdx.x; p < D * D; p += kThreads) part[(long long)blockIdx.x * D * D + p] = 0.;
+    __syncthreads();
+    for (long long i0 = blockIdx.x; i0 < n; i0 += (long long)kMomBlocks * kCovRows) {
+        // this block's next kCovRows rows: i0, i0 + kMomBlocks, ...
+        int nr = 0;
+        for (long long i = i0; i < n && nr < kCovRows; i += kMomBlocks) ++nr;
+        for (int e = threadIdx.x; e < nr * D; e += kThreads) {
+            const int r = e / D, d = e - r * D;
+            rows[e] = u[(long long)idx[i0 + (long long)r * kMomBlocks] * D + d] - ms[d];
         }
-        part[(long long)blockIdx.x * D * D + p] = s;
+        __syncthreads();
+        if (in_regs) {
+#pragma unroll
+            for (int q = 0; q < kPairs; ++q) {
+                const int p = threadIdx.x + q * kThreads;
+                if (p < D * D) {
+                    const int j = p / D, l = p - j * D;
+                    double acc = s[q];
+                    for (int r = 0; r < nr; ++r) acc += rows[r * D + j] * rows[r * D + l];
+                    s[q] = acc;
+                }
+            }
+        } else {
+            for (int p = threadIdx.x; p < D * D; p += kThreads) {
+                const int j = p / D, l = p - j * D;
+                double acc = part[(long long)blockIdx.x * D * D + p];
+                for (int r = 0; r < nr; ++r) acc += rows[r * D + j] * rows[r * D + l];
+                part[(long long)blockIdx.x * D * D + p] = acc;
+            }
+        }
+        __syncthreads();
     }
+    if (in_regs) {
+#pragma unroll
+        for (int q = 0; q < kPairs; ++q) {
+            const int p = threadIdx.x + q * kThreads;
+            if (p < D * D) part[(long long)blockIdx.x * D * D + p] = s[q];
+        }
+    }
+}
+
+// ---- the live points' order, on the device (rvll_live_sort) ----------------------------------------------------------------
+// log-L -> a key whose unsigned order is the doubles' order (the sign bit flipped for positives, every bit for negatives)
+__global__ __launch_bounds__(kThreads)
+void sort_keys_kernel(const double* logl, long long n, unsigned long long* keys, int32_t* rows)
+{
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(logl[i]);
+        keys[i] = (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+        rows[i] = (int32_t)i;
+    }
+}
+
+// out[i] = order[offset + rank[i]]
+__global__ __launch_bounds__(kThreads)
+void compose_index_kernel(const int32_t* order, long long offset, const int32_t* rank, long long n, int32_t* out)
+{
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < n; i += (long long)gridDim.x * kThreads)
+        out[i] = order[offset + rank[i]];
 }
 
 int blocks_for(long long total)
@@ -128,8 +190,37 @@ hipError_t launch_moments(const double* u, const int32_t* idx, long long n, int 
     double* part = scratch;
     hipLaunchKernelGGL(moments_sum_kernel, dim3(kMomBlocks), dim3(kThreads), 0, st, u, idx, n, D, part);
     hipLaunchKernelGGL(moments_fold_kernel, dim3(1), dim3(kThreads), 0, st, part, D, 1.0 / (double)n, mean);
-    hipLaunchKernelGGL(moments_cov_kernel, dim3(kMomBlocks), dim3(kThreads), 0, st, u, idx, n, D, mean, part);
+    hipLaunchKernelGGL(moments_cov_kernel, dim3(kMomBlocks), dim3(kThreads), sizeof(double) * ((size_t)kCovRows * D + D), st, u, idx, n, D, mean, part);
     hipLaunchKernelGGL(moments_fold_kernel, dim3(1), dim3(kThreads), 0, st, part, D * D, 1.0 / (double)(n > 1 ? n - 1 : 1), cov);
+    return hipGetLastError();
+}
+
+// Stable ascending order of logl[0..n) (ties by row, as numpy's stable argsort): keys / rows are scratch of n each (in and out),
+// temp of sort_temp_bytes(n) bytes; order_out[n] receives the rows, sorted_out[n] (or null) the sorted keys' log-L is not
+// returned — the caller gathers what it needs by index.
+size_t sort_temp_bytes(long long n)
+{
+    size_t bytes = 0;
+    unsigned long long* k = nullptr;
+    int32_t* v = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, (size_t)n, 0, 64, (hipStream_t) nullptr);
+    return bytes;
+}
+
+hipError_t launch_sort_logl(const double* logl, long long n, unsigned long long* keys_in, unsigned long long* keys_out, int32_t* rows_in,
+                            int32_t* order_out, void* temp, size_t temp_bytes, hipStream_t st)
+{
+    if (n <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(sort_keys_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, st, logl, n, keys_in, rows_in);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, rows_in, order_out, (size_t)n, 0, 64, st);
+}
+
+hipError_t launch_compose_index(const int32_t* order, long long offset, const int32_t* rank, long long n, int32_t* out, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(compose_index_kernel, dim3(blocks_for(n)), dim3(kThreads), 0, st, order, offset, rank, n, out);
     return hipGetLastError();
 }
 

@@ -144,7 +144,7 @@ __device__ __forceinline__ void rounds_step(const RoundsArgs& g, const int r, co
         //         them — accept the first candidate above lstar, shrink past the others (slice_walk_kernel's accept step)
         int state = w4.x, round = w4.y, nsp = w4.w;
         const int first = w4.z;
-        int acc = -1;
+        int acc = -1, accw = 0;
         long long used = 0;
         double newl = 0., tacc = 0.;
         if (r > 0 && state == 1) {
@@ -160,7 +160,7 @@ __device__ __forceinline__ void rounds_step(const RoundsArgs& g, const int r, co
                     used = -(long long)round0;
                     break;
                 }
-                if (cl > g.lstar) { state = 0; stp += 1; acc = j; newl = cl; tacc = t; break; }
+                if (cl > g.lstar) { state = 0; stp += 1; acc = j; newl = cl; tacc = t; accw = (s.rec_f[lane * SM + j] & RVLL_FLAG_WANDERED) ? 1 : 0; break; }
                 if (t < 0.) tmn = t; else tmx = t;
                 if (++round >= g.max_rounds) { state = 0; stp += 1; break; }     // give the move up, stay put
             }
@@ -197,7 +197,7 @@ __device__ __forceinline__ void rounds_step(const RoundsArgs& g, const int r, co
         if (valid) {
             reinterpret_cast<int4*>(g.ws)[i0 + lane] = make_int4(listed ? 1 : state, begins ? 0 : round, base + excl, S);
             g.step[i0 + lane] = stp;
-            if (acc >= 0) g.logl[i0 + lane] = newl;
+            if (acc >= 0) { g.logl[i0 + lane] = newl; g.wflag[i0 + lane] = accw; }
             if (listed && state == 1) { g.tmin[i0 + lane] = tmn; g.tmax[i0 + lane] = tmx; }
         }
         if (lane < W) {

@@ -343,7 +343,7 @@ __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx&
                         ++steps;
                     } while (fabs(dE) > a.tol && steps < kSafeSteps);
                 }
-                bool hit_itmax = false;
+                bool hit_itmax = false, wander = false;
                 // (Both this test and the redo pass of the tile are marked UNLIKELY, and that is worth 4 % of every launch: the
                 // register allocator weighs a value by the estimated frequency of the blocks that use it, and with the correctly
                 // rounded sin / cos in the redo pass — ~1000 instructions with scalar needs of their own — it spilled scalars
@@ -360,8 +360,12 @@ __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx&
                     int steps = shortcut ? kSafeSteps : 0;
                     if constexpr (CR) { E = M; steps = 0; }       // (the first eight steps seed where it ends as much as the later ones)
                     do {
+#ifdef RVLL_CR_FAKE                // (measurement builds only: the redo pass with the ordinary sin / cos — what the correctly rounded pair costs)
+                        sincos_any(E, s, c, kc);
+#else
                         if constexpr (CR) sincos_cr(E, s, c);
                         else              sincos_any(E, s, c, kc);
+#endif
                         const double f  = E - ec * s - M;
                         const double fp = 1 - ec * c;
                         const double En = E - div_exact(f, fp);
@@ -373,7 +377,7 @@ __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx&
                     // more than kSafeSteps steps: the iteration wandered (include/rvll.h, RVLL_FLAG_WANDERED)
                     if (steps > kSafeSteps) {
                         atomicOr(&cx.pflags[pl], RVLL_FLAG_WANDERED);
-                        if constexpr (!CR) atomicOr(cx.nfail, 2);            // the tile redoes this point's items (3b)
+                        if constexpr (!CR) { if (a.cr_redo) { atomicOr(cx.nfail, 2); wander = true; } }   // the tile redoes THIS item (3b)
                     }
 #ifdef RVLL_AB_PRIO
                     __builtin_amdgcn_s_setprio(0);
@@ -394,6 +398,11 @@ __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx&
                     const double den = __builtin_fma(-ec, c, 1.0);
                     const double num = __builtin_fma(p45.x, c - ec, -(p45.y * s));
                     rv = div_fast(num, den) + C0;
+                    // the first pass leaves an item with a wandering solve as NaN: the redo pass (3b) finds the item by it and
+                    // does it again with correctly rounded sin / cos — that item, not the 200 of its point: in a sampler's
+                    // candidates, unlike in prior draws, points with a planet at e >= 0.97 are common, and redoing whole points
+                    // cost the walk a third of its rate (profiles/r04_high_ecc_parity.txt)
+                    if constexpr (!CR && !FAILCHECK) { if (__builtin_expect(wander, 0)) rv = __builtin_nan(""); }
                 }
             } else {
                 // reduced precision: phase in fp64 (|M| ~ 1e4 rad, rvmodel:459), reduced to [-pi, pi]
@@ -937,7 +946,7 @@ __device__ __forceinline__ __attribute__((flatten)) void loglike_tile(const Logl
         if (__builtin_expect(L.nfail[0] != 0, 0)) {                // (cold: the register allocator is to favour the item loop)
             for (int i = base + tid; i < cend; i += NT) {
                 const int pl = i / a.Ne;
-                if (L.anyfail[pl] || (L.pflags[pl] & RVLL_FLAG_WANDERED))
+                if (L.anyfail[pl] || contrib[i - base] != contrib[i - base])       // a point with an itmax failure; an item left as NaN
                     contrib[i - base] = eval_item<PREC, true, EXTRAS, PREC == RVLL_PREC_FP64>(a, cx, pl, i - pl * a.Ne);
             }
             __syncthreads();

@@ -321,7 +321,11 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
                     used = -(round_of[pl] - j);
                     break;
                 }
-                if (cl > w.lstar) { state[pl] = 2; wl[pl] = cl; acc_slot[pl] = first + j; acc_g[pl] = gid[pl]; break; }
+                if (cl > w.lstar) {
+                    state[pl] = 2; wl[pl] = cl; acc_slot[pl] = first + j; acc_g[pl] = gid[pl];
+                    if (w.wflag) w.wflag[gid[pl]] = (fl & RVLL_FLAG_WANDERED) ? 1 : 0;
+                    break;
+                }
                 const double t = slot_t[first + j];
                 if (t < 0.) tmin[pl] = t; else tmax[pl] = t;
                 if (++round_of[pl] >= w.max_rounds) { state[pl] = 0; step_of[pl] += 1; break; }     // give the move up, stay put
@@ -680,7 +684,11 @@ void slice_walk_rows_kernel(const LoglikeArgs a, const WalkArgs w)
                     used = -(round_of[pl] - j);
                     break;
                 }
-                if (cl > w.lstar) { state[pl] = 2; wl[pl] = cl; acc_slot[pl] = first + j; acc_g[pl] = rrow[srow[pl]]; break; }
+                if (cl > w.lstar) {
+                    state[pl] = 2; wl[pl] = cl; acc_slot[pl] = first + j; acc_g[pl] = rrow[srow[pl]];
+                    if (w.wflag) w.wflag[rrow[srow[pl]]] = (fl & RVLL_FLAG_WANDERED) ? 1 : 0;
+                    break;
+                }
                 const double t = slot_t[first + j];
                 if (t < 0.) tmin[pl] = t; else tmax[pl] = t;
                 if (++round_of[pl] >= w.max_rounds) { state[pl] = 0; step_of[pl] += 1; break; }

@@ -22,7 +22,7 @@ int walk_reserve(rvll_handle* h, int64_t K)
         HIP_TRY(hipStreamSynchronize(h->compute));
         dev_free(h->d_walk_u); dev_free(h->d_walk_theta); dev_free(h->d_walk_logl);
         dev_free(h->d_walk_steps); dev_free(h->d_walk_wid); dev_free(h->d_walk_start);
-        dev_free(h->d_walk_cost); dev_free(h->d_walk_order);
+        dev_free(h->d_walk_cost); dev_free(h->d_walk_order); dev_free(h->d_walk_wflag);
         h->walk_cap = 0;
         const size_t cap = (size_t)std::max<long long>(K, 1024);
         HIP_TRY(hipMalloc(&h->d_walk_u, sizeof(double) * D * cap));
@@ -33,6 +33,7 @@ int walk_reserve(rvll_handle* h, int64_t K)
         HIP_TRY(hipMalloc(&h->d_walk_start, sizeof(int32_t) * cap));
         HIP_TRY(hipMalloc(&h->d_walk_cost, sizeof(int32_t) * cap));
         HIP_TRY(hipMalloc(&h->d_walk_order, sizeof(int32_t) * cap));
+        HIP_TRY(hipMalloc(&h->d_walk_wflag, sizeof(int32_t) * cap));
         if (!h->d_walk_chol) {
             HIP_TRY(hipMalloc(&h->d_walk_chol, sizeof(double) * D * D));
             HIP_TRY(hipMalloc(&h->d_walk_wrapped, sizeof(int32_t) * D));
@@ -136,6 +137,7 @@ int walk_rounds(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t
     }
     const size_t lds = fused ? std::max(rvll::loglike_lds_bytes(a), step_lds) : rvll::loglike_lds_bytes(a);
     const int tiles = (int)((C + a.PB - 1) / a.PB);
+    a.cr_redo = 0;                 // (the walk's tiles leave the exact redo of wandering solves to walk_core: see there)
     if (getenv("RVLL_WALK_GEOM_DUMP"))
         fprintf(stderr, "[rounds] K=%lld G=%d %s %s per=%lld C=%lld c_free=%lld W=%d step blocks=%lld PB=%d tiles=%d lds=%zu spec=%d\n", (long long)K, G,
                 fused ? "fused" : "streams", cu_form ? "cu" : "tile", per, C, c_free, W, nblk, a.PB, tiles, lds, spec);
@@ -184,7 +186,7 @@ int walk_rounds(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t
         const long long row0 = (long long)g * per, Kg = std::min<long long>(per, K - row0);
         rvll::RoundsArgs& r = ga[(size_t)g];
         r.u = h->d_walk_u + (size_t)row0 * D;  r.theta = h->d_walk_theta + (size_t)row0 * D;  r.logl = h->d_walk_logl + row0;
-        r.step = h->d_walk_steps + row0;
+        r.step = h->d_walk_steps + row0;  r.wflag = h->d_walk_wflag + row0;
         r.dir = d;                       d += (size_t)per * D;
         r.dirnext = d;                   d += (size_t)per * D;
         r.dirs = h->d_walk_dirs + (size_t)row0 * nsteps * D;
@@ -428,12 +430,20 @@ int walk_core(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t m
     hipStream_t st = h->compute;
     int rc;
     HIP_TRY(hipMemsetAsync(h->d_walk_ncalls, 0, kWalkWords * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(h->d_walk_wflag, 0, sizeof(int32_t) * (size_t)K, st));
     // the walk keeps per-walker state in LDS next to the tile's carve: shrink the group until both fit
     auto walk_args = [&](long long n, rvll::LoglikeArgs* a) -> int {
         int r = build_args(h, h->d_theta, h->d_logL2[0], h->d_flags2[0], n, a);
         if (r) return r;
         make_fused(h, h->d_cube, h->d_theta, a);
         a->defer = nullptr;                            // deferrals are per walker here (steps_done), not per batch
+        // A Kepler solve that wanders is 30 - 350 sequential Newton steps, and its exact redo (correctly rounded sin / cos in
+        // double-double, ~2 us a step per wave) holds up whatever waits for its tile — a whole round of the rounds form: with
+        // the redo inside the walk's tiles 1.65e8 calls/s became 1.04e8 (a candidate in ten thousand wanders; a round of 16384
+        // candidates nearly always has one).  So the walk's tiles evaluate such candidates with the ordinary sin / cos — the
+        // accept decision cannot tell the two values apart unless they straddle lstar, 1e-9 of |log-L| apart — and report which
+        // walkers END on one (w.wflag); their log-L is put right below, by the batch kernel, which carries the redo.
+        a->cr_redo = 0;
         auto window = [&](int pb) {                    // the tile's contribution window also holds 3 PB D doubles of the walk
             int ch = std::min(h->chunk_items, std::max(rvll::kThreads, pb * h->Ne));
             ch = std::max(ch, 3 * pb * a->D);
@@ -479,7 +489,7 @@ int walk_core(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t m
     rvll::WalkArgs w{h->d_walk_u, h->d_walk_theta, h->d_walk_logl, h->d_walk_chol, h->d_walk_wrapped, (long long)K,
                      nsteps, max_rounds, (unsigned long long)seed, lstar, h->d_walk_ncalls,
                      h->d_walk_steps, nullptr, nullptr, (long long)walker_base, spec, h->d_walk_ncalls + 1,
-                     h->d_walk_ncalls + kWalkWords - 1, nullptr, nullptr, 0};
+                     h->d_walk_ncalls + kWalkWords - 1, nullptr, nullptr, 0, h->d_walk_wflag};
     // no more workgroups than the chip holds at once; freed walker slots draw the remaining rows from a queue
     // (RVLL_WALK_QUEUE, a measurement / test switch: 0 = one workgroup per PB rows, as many residency rounds as that
     // takes; n > 0 = as many workgroups as n compute units hold, so that a small walk goes through the queue too)
@@ -607,7 +617,8 @@ int walk_core(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t m
     }
     unsigned long long evaluated[kWalkWords] = {};
     h->walk_evaluated = 0;
-    std::vector<int32_t> steps(slim ? (size_t)K : 0);
+    std::vector<int32_t> steps(slim ? (size_t)K : 0), wf((size_t)K);
+    HIP_TRY(hipMemcpyAsync(wf.data(), h->d_walk_wflag, sizeof(int32_t) * (size_t)K, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(evaluated, h->d_walk_ncalls, sizeof evaluated, hipMemcpyDeviceToHost, st));
     if (slim) HIP_TRY(hipMemcpyAsync(steps.data(), h->d_walk_steps, sizeof(int32_t) * (size_t)K, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
@@ -642,6 +653,9 @@ int walk_core(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t m
             HIP_TRY(hipMemcpyAsync(h->d_walk_logl, sl.data(), sizeof(double) * M, hipMemcpyHostToDevice, st));
             HIP_TRY(hipMemcpyAsync(h->d_walk_wid, ids.data(), sizeof(int32_t) * M, hipMemcpyHostToDevice, st));
             HIP_TRY(hipMemcpyAsync(h->d_walk_start, start.data(), sizeof(int32_t) * M, hipMemcpyHostToDevice, st));
+            std::vector<int32_t> wf_sub(M);
+            for (size_t j = 0; j < M; ++j) wf_sub[j] = wf[(size_t)ids[j]];
+            HIP_TRY(hipMemcpyAsync(h->d_walk_wflag, wf_sub.data(), sizeof(int32_t) * M, hipMemcpyHostToDevice, st));
             HIP_TRY(hipMemsetAsync(h->d_walk_ncalls, 0, kWalkWords * sizeof(unsigned long long), st));
             rvll::LoglikeArgs a2;
             rc = walk_args((long long)M, &a2);
@@ -654,6 +668,7 @@ int walk_core(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t m
             HIP_TRY(hipMemcpyAsync(su.data(), h->d_walk_u, sizeof(double) * D * M, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipMemcpyAsync(sth.data(), h->d_walk_theta, sizeof(double) * D * M, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipMemcpyAsync(sl.data(), h->d_walk_logl, sizeof(double) * M, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(wf_sub.data(), h->d_walk_wflag, sizeof(int32_t) * M, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipMemcpyAsync(evaluated, h->d_walk_ncalls, sizeof evaluated, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             total += (long long)evaluated[0];
@@ -663,11 +678,30 @@ int walk_core(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t m
                 memcpy(&hu[(size_t)ids[j] * D], &su[j * D], sizeof(double) * D);
                 memcpy(&hth[(size_t)ids[j] * D], &sth[j * D], sizeof(double) * D);
                 hl[(size_t)ids[j]] = sl[j];
+                wf[(size_t)ids[j]] = wf_sub[j];
             }
             HIP_TRY(hipMemcpyAsync(h->d_walk_u, hu.data(), sizeof(double) * D * (size_t)K, hipMemcpyHostToDevice, st));
             HIP_TRY(hipMemcpyAsync(h->d_walk_theta, hth.data(), sizeof(double) * D * (size_t)K, hipMemcpyHostToDevice, st));
             HIP_TRY(hipMemcpyAsync(h->d_walk_logl, hl.data(), sizeof(double) * (size_t)K, hipMemcpyHostToDevice, st));
             HIP_TRY(hipStreamSynchronize(st));
+        }
+    }
+    // the walkers that END on a candidate with a wandering solve: their log-L as the batch kernel gives it (the exact redo the
+    // walk's tiles leave out) — a handful of rows in a million candidates, gathered, evaluated, scattered back
+    if (h->wander_exact) {
+        std::vector<int32_t> rows;
+        for (int64_t i = 0; i < K; ++i) if (wf[(size_t)i]) rows.push_back((int32_t)i);
+        if (!rows.empty()) {
+            const int64_t n = (int64_t)rows.size();
+            HIP_TRY(hipMemcpyAsync(h->d_walk_order, rows.data(), sizeof(int32_t) * rows.size(), hipMemcpyHostToDevice, st));
+            HIP_TRY(rvll::launch_gather_rows(h->d_walk_theta, h->d_walk_order, n, (int)D, h->d_theta, st));
+            rvll::LoglikeArgs ax;
+            int cu = 0;
+            rc = build_args(h, h->d_theta, h->d_logL2[0], h->d_flags2[0], n, &ax, &cu);
+            if (rc) return rc;
+            HIP_TRY(cu > 0 ? rvll::launch_loglike_cu(ax, cu, st) : rvll::launch_loglike(ax, st));
+            HIP_TRY(rvll::launch_scatter_rows(h->d_logL2[0], h->d_walk_order, n, 1, h->d_walk_logl, st));
+            HIP_TRY(hipStreamSynchronize(st));         // `rows` goes out of scope
         }
     }
     if (ncalls) *ncalls = (int64_t)total;
@@ -741,6 +775,7 @@ int rvll_live_init(rvll_handle* h, const double* cube, int64_t N, double* logl_o
     // rvll_live_get refuse live_n = 0) — live_n is set again as the last thing, on success
     h->live_n = 0;
     h->dead_n = 0;
+    h->sorted_kdead = -1;
     const size_t D = (size_t)std::max(1, h->L.ndim);
     rc = rvll_dev_upload_cube(h, cube, N);
     if (rc) return rc;
@@ -752,11 +787,14 @@ int rvll_live_init(rvll_handle* h, const double* cube, int64_t N, double* logl_o
     if (rc) return rc;
     if (N > h->live_cap) {
         dev_free(h->d_live_u); dev_free(h->d_live_theta); dev_free(h->d_live_logl); dev_free(h->d_live_idx);
+        dev_free(h->d_sort_keys); dev_free(h->d_sort_rows);
         h->live_cap = 0;
         HIP_TRY(hipMalloc(&h->d_live_u, sizeof(double) * D * (size_t)N));
         HIP_TRY(hipMalloc(&h->d_live_theta, sizeof(double) * D * (size_t)N));
         HIP_TRY(hipMalloc(&h->d_live_logl, sizeof(double) * (size_t)N));
         HIP_TRY(hipMalloc(&h->d_live_idx, sizeof(int32_t) * 2 * (size_t)N));
+        HIP_TRY(hipMalloc(&h->d_sort_keys, sizeof(unsigned long long) * 2 * (size_t)N));
+        HIP_TRY(hipMalloc(&h->d_sort_rows, sizeof(int32_t) * (size_t)N));
         h->live_cap = N;
     }
     if (!h->d_live_mom) HIP_TRY(hipMalloc(&h->d_live_mom, sizeof(double) * (rvll::moments_scratch_doubles((int)D) + D + D * D)));
@@ -780,12 +818,20 @@ int rvll_live_step(rvll_handle* h, const int32_t* order, int64_t kdead, const in
     if (ncalls) *ncalls = 0;
     const int64_t N = h->live_n;
     if (N < 1) return report_error(RVLL_E_INVALID, "rvll_live_init has not been called");
-    if (!order || !start || !logl_new || kdead < 1 || kdead >= N) return report_error(RVLL_E_INVALID, "rvll_live_step: bad arguments");
+    if (!start || !logl_new || kdead < 1 || kdead >= N) return report_error(RVLL_E_INVALID, "rvll_live_step: bad arguments");
     rc = walk_check_args(h, kdead, nsteps, max_rounds, walker_base);
     if (rc) return rc;
-    for (int64_t i = 0; i < N; ++i)
+    const bool dev_order = order == nullptr;             // the order rvll_live_sort left on the device; start[] are ranks among the survivors
+    if (dev_order) {
+        if (h->sorted_kdead != kdead) return report_error(RVLL_E_INVALID, "rvll_live_step: order is NULL but no rvll_live_sort(kdead = %lld) precedes", (long long)kdead);
+        if (!(lstar == h->sorted_lstar)) return report_error(RVLL_E_INVALID, "rvll_live_step: lstar is not the one rvll_live_sort returned");
+        for (int64_t i = 0; i < kdead; ++i)
+            if (start[i] < 0 || start[i] >= N - kdead) return report_error(RVLL_E_INVALID, "rvll_live_step: start[%lld] is not a rank among the survivors", (long long)i);
+        h->sorted_kdead = -1;                            // (used up, whatever happens below: the step changes the rows)
+    }
+    for (int64_t i = 0; !dev_order && i < N; ++i)
         if (order[i] < 0 || order[i] >= N) return report_error(RVLL_E_INVALID, "rvll_live_step: order[%lld] out of range", (long long)i);
-    {
+    if (!dev_order) {
         // the dying rows are scattered into in parallel and appended to the dead store: a row listed twice would race and be counted twice
         std::vector<uint64_t> seen(((size_t)N + 63) / 64, 0);
         for (int64_t i = 0; i < kdead; ++i) {
@@ -795,7 +841,7 @@ int rvll_live_step(rvll_handle* h, const int32_t* order, int64_t kdead, const in
             word |= bit;
         }
     }
-    for (int64_t i = 0; i < kdead; ++i)
+    for (int64_t i = 0; !dev_order && i < kdead; ++i)
         if (start[i] < 0 || start[i] >= N) return report_error(RVLL_E_INVALID, "rvll_live_step: start[%lld] out of range", (long long)i);
     const size_t D = (size_t)h->L.ndim;
     const int Di = h->L.ndim;
@@ -804,8 +850,15 @@ int rvll_live_step(rvll_handle* h, const int32_t* order, int64_t kdead, const in
     hipStream_t st = h->compute;
     int32_t* d_order = h->d_live_idx;
     int32_t* d_start = h->d_live_idx + h->live_cap;
-    HIP_TRY(hipMemcpyAsync(d_order, order, sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_start, start, sizeof(int32_t) * (size_t)kdead, hipMemcpyHostToDevice, st));
+    if (dev_order) {
+        // d_order holds the device's own order; the ranks go up through the sort's row scratch and become rows on the device
+        HIP_TRY(hipMemcpyAsync(h->d_sort_rows, start, sizeof(int32_t) * (size_t)kdead, hipMemcpyHostToDevice, st));
+        HIP_TRY(rvll::launch_compose_index(d_order, kdead, h->d_sort_rows, kdead, d_start, st));
+    } else {
+        h->sorted_kdead = -1;
+        HIP_TRY(hipMemcpyAsync(d_order, order, sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_start, start, sizeof(int32_t) * (size_t)kdead, hipMemcpyHostToDevice, st));
+    }
     // the points that die (rows order[0 .. kdead)) go to the dead store before their rows are overwritten
     if (h->dead_n + kdead > h->dead_cap) {
         const long long cap = std::max<long long>(2 * h->dead_cap, h->dead_n + 4 * kdead);
@@ -876,6 +929,42 @@ int rvll_live_step(rvll_handle* h, const int32_t* order, int64_t kdead, const in
     HIP_TRY(hipMemcpyAsync(logl_new, h->d_walk_logl, sizeof(double) * (size_t)kdead, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     h->dead_n += kdead;
+    return RVLL_OK;
+}
+
+int rvll_live_sort(rvll_handle* h, int64_t kdead, double* dead_logl, double* lstar, double* max_logl)
+{
+    int rc = use_device(h);
+    if (rc) return rc;
+    const int64_t N = h->live_n;
+    if (N < 1) return report_error(RVLL_E_INVALID, "rvll_live_init has not been called");
+    if (kdead < 1 || kdead >= N || !dead_logl || !lstar || !max_logl) return report_error(RVLL_E_INVALID, "rvll_live_sort: bad arguments");
+    h->sorted_kdead = -1;
+    hipStream_t st = h->compute;
+    const size_t need = rvll::sort_temp_bytes(N);
+    if (need > h->sort_temp_bytes) {
+        HIP_TRY(hipStreamSynchronize(st));
+        dev_free(h->d_sort_temp);
+        h->sort_temp_bytes = 0;
+        HIP_TRY(hipMalloc(&h->d_sort_temp, need));
+        h->sort_temp_bytes = need;
+    }
+    int32_t* d_order = h->d_live_idx;
+    HIP_TRY(rvll::launch_sort_logl(h->d_live_logl, N, h->d_sort_keys, h->d_sort_keys + h->live_cap, h->d_sort_rows, d_order,
+                                   h->d_sort_temp, h->sort_temp_bytes, st));
+    // the log-L of the kdead lowest, in order, and of the highest: gathered into the walk's log-L scratch, one download
+    rc = walk_reserve(h, kdead + 1);
+    if (rc) return rc;
+    HIP_TRY(rvll::launch_gather_rows(h->d_live_logl, d_order, kdead, 1, h->d_walk_logl, st));
+    HIP_TRY(rvll::launch_gather_rows(h->d_live_logl, d_order + (N - 1), 1, 1, h->d_walk_logl + kdead, st));
+    std::vector<double> got((size_t)kdead + 1);
+    HIP_TRY(hipMemcpyAsync(got.data(), h->d_walk_logl, sizeof(double) * ((size_t)kdead + 1), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    memcpy(dead_logl, got.data(), sizeof(double) * (size_t)kdead);
+    *lstar = got[(size_t)kdead - 1];
+    *max_logl = got[(size_t)kdead];
+    h->sorted_kdead = kdead;
+    h->sorted_lstar = *lstar;
     return RVLL_OK;
 }
 

@@ -333,12 +333,12 @@ class GpuRVModel:
         die (kept in the device's dead store), kdead walkers start from rows `start`, walk, and replace them.  chol=None:
         the whitening comes from the surviving rows' covariance, computed on the device.  Returns (logl_new[kdead], ncalls)
         (+ the factor used with return_chol)."""
-        order = np.ascontiguousarray(order, dtype=np.int32)
+        order = None if order is None else np.ascontiguousarray(order, dtype=np.int32)     # None: the order live_sort left on the device
         start = np.ascontiguousarray(start, dtype=np.int32)
         kdead = int(kdead)
         if self._live_n < 1:
             raise RuntimeError("live_init has not been called")
-        if order.shape != (self._live_n,) or start.shape != (kdead,):
+        if (order is not None and order.shape != (self._live_n,)) or start.shape != (kdead,):
             raise ValueError("order must list every live row, start one row per dying point")
         wr = None if wrapped is None else np.ascontiguousarray(np.asarray(wrapped, dtype=bool).astype(np.int32))
         ch = None if chol is None else np.ascontiguousarray(chol, dtype=np.float64)
@@ -348,10 +348,22 @@ class GpuRVModel:
         used = np.empty((self.ndim, self.ndim)) if return_chol else None
         ncalls = C.c_int64(0)
         _abi.check(self._lib.rvll_live_step(
-            self._h, _abi.as_ip(order), kdead, _abi.as_ip(start), float(lstar), _abi.as_dp(ch) if ch is not None else None,
+            self._h, _abi.as_ip(order) if order is not None else None, kdead, _abi.as_ip(start), float(lstar), _abi.as_dp(ch) if ch is not None else None,
             _abi.as_ip(wr) if wr is not None else None, int(nsteps), int(max_rounds), int(seed) & (2 ** 64 - 1),
             int(walker_base), C.byref(ncalls), _abi.as_dp(logl_new), _abi.as_dp(used) if used is not None else None))
         return (logl_new, int(ncalls.value), used) if return_chol else (logl_new, int(ncalls.value))
+
+    def live_sort(self, kdead):
+        """Sort the resident live points by log-L ON THE DEVICE (include/rvll.h, rvll_live_sort): returns (log-L of the kdead
+        lowest in ascending order, lstar = the kdead-th lowest, the highest log-L).  The live_step that follows is called with
+        order=None and `start` as ranks among the survivors."""
+        kdead = int(kdead)
+        if self._live_n < 1:
+            raise RuntimeError("live_init has not been called")
+        dead = np.empty(kdead, dtype=np.float64)
+        lstar, top = C.c_double(), C.c_double()
+        _abi.check(self._lib.rvll_live_sort(self._h, kdead, _abi.as_dp(dead), C.byref(lstar), C.byref(top)))
+        return dead, lstar.value, top.value
 
     def live_get(self, cube=True, theta=True, logl=True, theta_out=None):
         """(cube, theta, logl) of the resident live set (None for the ones switched off); theta_out: a C-contiguous
@@ -456,6 +468,11 @@ class GpuRVModel:
     def set_slim_table_range(self, umax):
         """Test hook (include/rvll.h): |logit q| range the table-only prior stage takes before handing over."""
         _abi.check(self._lib.rvll_set_slim_table_range(self._h, float(umax)))
+
+    def set_wander_exact(self, on=True):
+        """Redo wandering Kepler solves (e >= 0.97: more than eight Newton steps) with correctly rounded sin / cos (include/rvll.h,
+        rvll_set_wander_exact; default on)."""
+        _abi.check(self._lib.rvll_set_wander_exact(self._h, 1 if on else 0))
 
     def set_walk_speculation(self, max_ahead):
         """Candidates a walker of slice_walk may evaluate ahead per iteration in otherwise free tile slots (include/rvll.h;

@@ -220,12 +220,25 @@ def run_nested_slice(prior: Callable, loglike: Callable, ndim: int, nlive: Optio
     dead_theta, dead_logl, dead_logw = [], [], []
     logz, h, logx = -np.inf, 0.0, 0.0
     it = 0
+    # the resident live set with the ORDER on the device as well (GpuRVModel.live_sort, round 4): no per-point state on the host
+    # at all — per iteration the log-L of the dying points comes down (the evidence sums need them), ranks go up
+    device_order = live is not None and u is None and hasattr(live, "live_sort")
+    top = float(np.max(logl)) if device_order else None
     while it < max_iter and ncall < max_calls:
-        order = _stable_argsort(logl)
-        dead = order[:kbatch]
-        lstar = logl[dead[-1]]
-        dl = logl[dead]
-        if live is not None and u is None:
+        if device_order:
+            dl, lstar, top = live.live_sort(kbatch)
+            ranks = rng.integers(0, nlive - kbatch, kbatch)          # (the draw the host order's alive[rng.integers(...)] makes)
+            seed_it = int(rng.integers(0, 2 ** 62))
+            pending = _helper().submit(live.live_step, None, kbatch, ranks, lstar, wrapped, nsteps, 200, seed_it)
+            order = dead = None
+        else:
+            order = _stable_argsort(logl)
+            dead = order[:kbatch]
+            lstar = logl[dead[-1]]
+            dl = logl[dead]
+        if device_order:
+            pass
+        elif live is not None and u is None:
             # the resident live set, whitening on the device: the walk needs nothing of this iteration's evidence
             # bookkeeping, so it starts first — on a helper thread (the C call releases the interpreter lock) — and the
             # vectorised sums below run on the host while the GPU walks
@@ -254,8 +267,12 @@ def run_nested_slice(prior: Callable, loglike: Callable, ndim: int, nlive: Optio
         if pending is not None:
             wl, used = pending.result()
             ncall += int(used)
-            logl[dead] = wl
-            if np.max(logl) + logx < logz + np.log(np.expm1(dlogz)):
+            if device_order:
+                top = max(top, float(np.max(wl)))                     # the survivors' highest and the newcomers'
+            else:
+                logl[dead] = wl
+                top = np.max(logl)
+            if top + logx < logz + np.log(np.expm1(dlogz)):
                 break
             continue
         alive = order[kbatch:]
@@ -311,6 +328,8 @@ def run_nested_slice(prior: Callable, loglike: Callable, ndim: int, nlive: Optio
         u[dead], theta[dead], logl[dead] = wu, wt, wl
         if np.max(logl) + logx < logz + np.log(np.expm1(dlogz)):
             break
+    if device_order:
+        logl = live.live_get(cube=False, theta=False)[2]              # the live points' log-L: once, at the end
     logw_live = logx - np.log(nlive) + logl
     logz_final = np.logaddexp(logz, _logaddexp_many(logw_live))
     if live is not None and hasattr(live, "live_dead_count"):

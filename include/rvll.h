@@ -283,14 +283,23 @@ int rvll_slice_walk_rounds(rvll_handle* h, int32_t* rounds);
  *                  order[i]).  chol: the whitening factor [ndim, ndim], or NULL to have the covariance of the surviving
  *                  rows summed on the device (two passes, fixed order) and factored by the library; chol_out (may be
  *                  NULL) receives the factor that was used.  logl_new [kdead]: the new log-L of rows order[0 .. kdead).
+ * rvll_live_sort   (round 4) the order itself, on the device: the live rows by ascending log-L (stable: ties by row, as
+ *                  numpy's stable argsort) are sorted there and stay there; dead_logl [kdead] receives the log-L of the kdead
+ *                  lowest in that order (the sampler's evidence sums need them), *lstar the kdead-th lowest, *max_logl the
+ *                  highest.  The rvll_live_step that follows is then called with order = NULL, and its start [kdead] are
+ *                  RANKS among the survivors (0 .. N - kdead - 1; the sampler's random draw): walker i starts from the row
+ *                  of rank start[i].  A sampler then mirrors nothing per live point on the host: per iteration kdead ranks go
+ *                  up, 2 kdead log-L values come down (0.6 ms of host sort and 128 KB of order per iteration at 32768 live
+ *                  points before).
  * rvll_live_get    the live set as it stands (any pointer may be NULL).
  * rvll_live_dead   *n_dead in: capacity of theta [*, ndim] / logl [*] in rows (ignored when both are NULL);
  *                  out: rows in the dead store.  Rows are in the order they died.                                     */
 int rvll_live_init(rvll_handle* h, const double* cube /*[N, ndim]*/, int64_t N, double* logl_out /*[N] or NULL*/);
-int rvll_live_step(rvll_handle* h, const int32_t* order /*[N]*/, int64_t kdead, const int32_t* start /*[kdead]*/,
+int rvll_live_step(rvll_handle* h, const int32_t* order /*[N], or NULL after rvll_live_sort*/, int64_t kdead, const int32_t* start /*[kdead]*/,
                    double lstar, const double* chol /*[ndim, ndim] or NULL*/, const int32_t* wrapped /*[ndim] or NULL*/,
                    int32_t nsteps, int32_t max_rounds, uint64_t seed, int64_t walker_base, int64_t* ncalls,
                    double* logl_new /*[kdead]*/, double* chol_out /*[ndim, ndim] or NULL*/);
+int rvll_live_sort(rvll_handle* h, int64_t kdead, double* dead_logl /*[kdead]*/, double* lstar, double* max_logl);
 int rvll_live_get(rvll_handle* h, double* cube, double* theta, double* logl);
 int rvll_live_dead(rvll_handle* h, int64_t* n_dead, double* theta, double* logl);
 
@@ -437,6 +446,14 @@ int rvll_debug_eval(rvll_handle* h, int32_t op, const double* x, const double* y
 int rvll_dev_trace_loglike(rvll_handle* h, int64_t B, int32_t warmup, uint64_t* out, int64_t out_words,
                            int32_t* blocks, int32_t* points_per_block);
 
+/* The exact redo of wandering Kepler solves (round 4; default on; RVLL_WANDER_EXACT=0 in the environment at rvll_create turns it
+ * off).  Started at E = M next to a zero of 1 - e cos E (e >= 0.97) the reference's Newton iteration wanders for 30 - 350 steps,
+ * and where it stops hangs on the last bit of every sin / cos on the way.  With the switch on, a solve that takes
+ * more than eight steps is done again from its start with correctly rounded sin / cos — what glibc's are nearly always — and
+ * the device is within 1e-10 of the reference on all but ~0.01 % of points with a planet at e >= 0.97 (1.4 % without; the
+ * points still carry RVLL_FLAG_WANDERED).  Costs nothing where no solve wanders.  The proposal walk evaluates its CANDIDATES
+ * without the redo (a wandering solve would hold a whole round up) and puts the log-L of the points it ENDS on right.   */
+int rvll_set_wander_exact(rvll_handle* h, int32_t on);
 /* The kernels that carry a log-L tile next to the prior stage (one-launch cube -> log-L, the walk) evaluate Beta /
  * Gamma quantiles by their verified tables over |logit q| <= umax (default: the whole table, 30) and hand every
  * other element to the routines with the full solvers — same results either way.  Lowering umax (0: nothing is

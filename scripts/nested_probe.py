@@ -32,6 +32,8 @@ with GpuRVModel(w.fixedpardict, w.table, w.parnames, priordict=w.priordict()) as
 
             class Live:
                 live_init, live_get, live_dead, live_dead_count = m.live_init, m.live_get, m.live_dead, m.live_dead_count
+                if not os.environ.get('PROBE_HOST_SORT'):
+                    live_sort = m.live_sort
 
                 @staticmethod
                 def live_step(*a, **k):

@@ -416,6 +416,21 @@ def test_live_step_api_contract(gpu_required):
     d0 = cube[keep] - cube[keep].mean(axis=0)
     want = np.linalg.cholesky(d0.T @ d0 / (len(keep) - 1) + 1e-14 * np.eye(m.ndim))
     assert np.allclose(chol, want, rtol=1e-10, atol=1e-13) and np.allclose(np.triu(chol, 1), 0.0)
+    # the order on the device (rvll_live_sort, round 4): the same step from ranks among the survivors instead of an order and rows
+    with GpuRVModel(w.fixedpardict, w.table, w.parnames, priordict=w.priordict()) as m:
+        logl2 = m.live_init(cube)
+        dl, lstar2, top = m.live_sort(k)
+        assert np.array_equal(dl, logl[order[:k]]) and lstar2 == lstar and top == logl.max() and np.array_equal(logl2, logl)
+        ranks = np.searchsorted(order[k:], start) if False else np.array([int(np.flatnonzero(order[k:] == s)[0]) for s in start])
+        new2, used3 = m.live_step(None, k, ranks, lstar2, wr, nsteps=6, seed=12, chol=chol)
+        u2, theta2, ll2 = m.live_get()
+        assert used3 == used and np.array_equal(new2, new) and np.array_equal(u2, u) and np.array_equal(theta2, theta) and np.array_equal(ll2, ll)
+        with pytest.raises(Exception, match="rvll_live_sort"):       # the order is used up: a second step needs a second sort
+            m.live_step(None, k, ranks, lstar2, wr, nsteps=6, seed=12, chol=chol)
+        ties = np.round(cube[:, :1] * 4) / 4 + 0 * cube            # many equal log-L values: ties go by row, as numpy's stable argsort
+        lt = m.live_init(np.clip(ties, 0.0, 0.999))
+        dl_t, _, _ = m.live_sort(k)
+        assert np.array_equal(dl_t, lt[np.argsort(lt, kind="stable")[:k]])
     # a step that fails leaves the run as it was: a dying row listed twice is refused before anything is touched; a
     # covariance that cannot be factored (a NaN among the surviving rows) fails AFTER the dying rows were copied to the dead
     # store — which must not count them, or a retry would append them again
@@ -466,3 +481,48 @@ def test_converged_evidence_resident_against_host_managed(gpu_required):
             assert 0.05 < res.logzerr < 0.3 and 20 < res.information < 40
             assert abs(res.logz - host.logz) < 3 * np.hypot(res.logzerr, host.logzerr), (seed, res.logz, host.logz, res.logzerr)
             assert -540 < res.logz < -532
+
+
+def test_walkers_that_end_on_a_wandering_solve_carry_the_exact_log_l(gpu_required, monkeypatch):
+    """Round 4: a Kepler solve that wanders (e >= 0.97) is redone with correctly rounded sin / cos by every batch path
+    (rvll_set_wander_exact) — but not inside the walk's tiles, where one such solve would hold a whole round up: the walk
+    judges its candidates by the ordinary evaluation and puts the log-L of the points it ENDS on right afterwards.  On a
+    model whose first planet lives at e = 0.95 .. 0.9925 (most candidates wander): every end point's log-L is the batch
+    path's, bit for bit; the rounds form and the single-kernel form agree; and with the switch off the walk ends on the
+    same positions with log-L values that differ on the wandering points by parts in 1e10."""
+    import golden
+    from evidence_amd import priors as P
+    case = golden.high_ecc_case()
+    lo, hi = case.theta.min(axis=0), case.theta.max(axis=0)
+    pri = {n: P.Uniform(float(a), float(b if b > a else a + 1.0)) for n, a, b in zip(case.parnames, lo, hi)}
+    pri["planet1_ecc"] = P.Uniform(0.95, 0.9925)
+    out = {}
+    for exact in (True, False):
+        with GpuRVModel(case.fixed, case.table, case.parnames, priordict=pri) as m:
+            m.set_wander_exact(exact)
+            rng = np.random.default_rng(5)
+            cube = rng.random((6000, m.ndim))
+            theta, logl = m.prior_loglike_batch(cube)
+            lstar = float(np.quantile(logl, 0.5))
+            keep = logl > lstar
+            cube, theta, logl = cube[keep], theta[keep], logl[keep]
+            d0 = cube - cube.mean(axis=0)
+            chol = np.linalg.cholesky(d0.T @ d0 / (len(cube) - 1) + 1e-14 * np.eye(m.ndim))
+            wr = wrapped_params(m.parnames)
+            for form in ("0", "1"):
+                monkeypatch.setenv("RVLL_WALK_ROUNDS", form)
+                c2, t2, l2, n = m.slice_walk(cube, theta, logl, lstar, chol, wr, nsteps=6, seed=3)
+                th_chk, ll_chk = m.prior_loglike_batch(c2)
+                assert np.array_equal(th_chk, t2) and np.array_equal(ll_chk, l2), (exact, form)
+                out[(exact, form)] = (c2, l2, n)
+            monkeypatch.delenv("RVLL_WALK_ROUNDS")
+            out[(exact, "flags")] = m.log_likelihood_batch(m.prior_transform_batch(out[(exact, "0")][0]), return_flags=True)[1]
+    for exact in (True, False):
+        a, b = out[(exact, "0")], out[(exact, "1")]
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    on, off = out[(True, "0")], out[(False, "0")]
+    assert np.array_equal(on[0], off[0]) and on[2] == off[2]                 # the same walk ...
+    wandered = (out[(True, "flags")] & 4) != 0
+    assert wandered.mean() > 0.2 and np.array_equal(on[1][~wandered], off[1][~wandered])
+    diff = np.abs(on[1] - off[1]) / np.abs(on[1])
+    assert 0 < diff[wandered].max() < 1e-8 and (diff[wandered] > 0).mean() > 0.01   # ... whose wandering end points carry the exact values

@@ -125,11 +125,27 @@ class _HostLive:
         self.u[dead], self.theta[dead], self.logl[dead] = wu, wt, wl
         return wl.copy(), used
 
-    def live_get(self):
-        return self.u.copy(), self.theta.copy(), self.logl.copy()
+    def live_get(self, cube=True, theta=True, logl=True):
+        return (self.u.copy() if cube else None, self.theta.copy() if theta else None, self.logl.copy() if logl else None)
 
     def live_dead(self):
         return np.vstack(self.dead_theta), np.concatenate(self.dead_logl)
+
+
+class _HostLiveSorting(_HostLive):
+    """... with the ORDER kept by the stand-in as well (GpuRVModel.live_sort, round 4): the driver sends ranks among the
+    survivors and never sees the order."""
+
+    def live_sort(self, kdead):
+        self.order = np.argsort(self.logl, kind="stable")
+        self.sorted_for = kdead
+        dl = self.logl[self.order[:kdead]]
+        return dl.copy(), float(dl[-1]), float(self.logl[self.order[-1]])
+
+    def live_step(self, order, kdead, start, lstar, *a, **k):
+        assert order is None and self.sorted_for == kdead and lstar == self.logl[self.order[kdead - 1]]
+        self.sorted_for = None
+        return super().live_step(self.order, kdead, self.order[kdead:][np.asarray(start)], lstar, *a, **k)
 
 
 @pytest.mark.parametrize("live_chol", ["device", "host"])
@@ -157,5 +173,12 @@ def test_resident_live_set_path_is_the_walker_path(live_chol):
     assert got.niter == ref.niter and got.ncall == ref.ncall and got.logz == ref.logz and got.information == ref.information
     assert np.array_equal(got.samples, ref.samples) and np.array_equal(got.logl, ref.logl) and np.array_equal(got.logwt, ref.logwt)
     assert len(live.calls) == ref.niter // 100 and all(k == 100 for k, _, _ in live.calls)
+    if live_chol == "device":
+        # the order on the "device" too: the driver keeps no per-point state at all, and it is still the same run
+        sorting = _HostLiveSorting(prior, loglike, walk)
+        got2 = run_nested_slice(None, None, 3, live=sorting, **kw)
+        assert got2.niter == ref.niter and got2.ncall == ref.ncall and got2.logz == ref.logz and got2.information == ref.information
+        assert np.array_equal(got2.samples, ref.samples) and np.array_equal(got2.logl, ref.logl) and np.array_equal(got2.logwt, ref.logwt)
+        assert sorting.calls == live.calls
     with pytest.raises(ValueError):
         run_nested_slice(None, None, 3, live=live, live_chol="elsewhere", **kw)
