@@ -476,6 +476,27 @@ RVLL_HD void rotate_small(double h, double& s, double& c)
     c = c0 + __builtin_fma(c0, ch1, -(s0 * sh));
 }
 
+// (sin r, cos r) of the reduced argument -> (sin x, cos x) by the quadrant: swap and signs with bit operations (compare +
+// v_cndmask cost ~4 cycles each, measured)
+RVLL_HD void quadrant_f32(float sr, float cr, uint32_t uq, float& s_out, float& c_out)
+{
+    const uint32_t m = 0u - (uq & 1u);
+    const uint32_t sb = __builtin_bit_cast(uint32_t, sr), cb = __builtin_bit_cast(uint32_t, cr);
+    uint32_t rs, rc;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_bfi_b32 %0, %2, %4, %3\n\t"
+        "v_bfi_b32 %1, %2, %3, %4"
+        : "=&v"(rs), "=&v"(rc) : "v"(m), "v"(sb), "v"(cb));
+#else
+    rs = (cb & m) | (sb & ~m);
+    rc = (sb & m) | (cb & ~m);
+#endif
+    rs ^= (uq & 2u) << 30;
+    rc ^= ((uq + 1u) & 2u) << 30;
+    s_out = __builtin_bit_cast(float, rs);
+    c_out = __builtin_bit_cast(float, rc);
+}
+
 // ---- fp32 pieces of the reduced-precision modes (RVLL_PREC_MIXED / RVLL_PREC_FP32) ----------
 // sin and cos of a float in roughly [-8, 8] (a mean anomaly already reduced to [-pi, pi] in fp64,
 // plus Newton steps): one Cody-Waite step to [-pi/4, pi/4], degree-7/8 minimax kernels
@@ -495,23 +516,7 @@ RVLL_HD void sincos_f32(float x, float& s_out, float& c_out)
     pc = __builtin_fmaf(z, pc, 4.1666623323739063189e-02f);
     pc = __builtin_fmaf(z, pc, -0.5f);
     const float cr = __builtin_fmaf(z, pc, 1.0f);
-    // quadrant swap and signs with bit operations (compare + v_cndmask cost ~4 cycles each, measured)
-    const uint32_t uq = (uint32_t)q;
-    const uint32_t m = 0u - (uq & 1u);
-    const uint32_t sb = __builtin_bit_cast(uint32_t, sr), cb = __builtin_bit_cast(uint32_t, cr);
-    uint32_t rs, rc;
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm("v_bfi_b32 %0, %2, %4, %3\n\t"
-        "v_bfi_b32 %1, %2, %3, %4"
-        : "=&v"(rs), "=&v"(rc) : "v"(m), "v"(sb), "v"(cb));
-#else
-    rs = (cb & m) | (sb & ~m);
-    rc = (sb & m) | (cb & ~m);
-#endif
-    rs ^= (uq & 2u) << 30;
-    rc ^= ((uq + 1u) & 2u) << 30;
-    s_out = __builtin_bit_cast(float, rs);
-    c_out = __builtin_bit_cast(float, rc);
+    quadrant_f32(sr, cr, (uint32_t)q, s_out, c_out);
 }
 
 // x reduced to [-pi, pi] in fp64 (two-constant Cody-Waite on 2*pi), returned as float.
@@ -535,6 +540,51 @@ RVLL_HD float div_f32(float n, float d)
     return __builtin_fmaf(__builtin_fmaf(-d, q, n), y, q);             // one residual step
 #else
     return n / d;
+#endif
+}
+
+// ---- the same, two at a time (the reduced-precision modes' item pairs, rvll_tile.h eval_item_pair) ---------------------------
+// Two items per lane, their arithmetic in v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: a wave of single items ran one dependent
+// chain per lane and was bound by the latency of that chain, not by the VALUs' rate (PMC: the fp32 kernel issued as many
+// vector instructions as the fp64 one and each took as long; profiles/r04_precision_modes.txt).  Component k of every result
+// is exactly what the scalar routine above returns for component k.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+RVLL_HD f32x2 splat2(float v) { return f32x2{v, v}; }
+RVLL_HD f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+RVLL_HD void sincos_f32x2(f32x2 x, f32x2& s_out, f32x2& c_out)
+{
+    const f32x2 t = x * splat2(6.36619772367581382433e-01f);
+    const f32x2 fk = {__builtin_rintf(t.x), __builtin_rintf(t.y)};
+    const int q0 = (int)fk.x, q1 = (int)fk.y;
+    f32x2 r = fma2(-fk, splat2(1.5707963109016418e+00f), x);
+    r = fma2(-fk, splat2(1.5893254773528196e-08f), r);
+    const f32x2 z = r * r;
+    f32x2 ps = fma2(z, splat2(2.7183114939898219064e-06f), splat2(-1.9839334836096632576e-04f));
+    ps = fma2(z, ps, splat2(8.3333293858894631756e-03f));
+    ps = fma2(z, ps, splat2(-1.6666666641626524e-01f));
+    const f32x2 sr = fma2(r * z, ps, r);
+    f32x2 pc = fma2(z, splat2(2.4390448796277409065e-05f), splat2(-1.3886763774609929416e-03f));
+    pc = fma2(z, pc, splat2(4.1666623323739063189e-02f));
+    pc = fma2(z, pc, splat2(-0.5f));
+    const f32x2 cr = fma2(z, pc, splat2(1.0f));
+    float s0, c0, s1, c1;
+    quadrant_f32(sr.x, cr.x, (uint32_t)q0, s0, c0);
+    quadrant_f32(sr.y, cr.y, (uint32_t)q1, s1, c1);
+    s_out = f32x2{s0, s1};
+    c_out = f32x2{c0, c1};
+}
+
+RVLL_HD f32x2 div_f32x2(f32x2 n, f32x2 d)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const f32x2 y = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    const f32x2 q = n * y;
+    return fma2(fma2(-d, q, n), y, q);
+#else
+    return f32x2{n.x / d.x, n.y / d.y};
 #endif
 }
 

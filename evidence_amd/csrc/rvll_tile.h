@@ -278,7 +278,7 @@ struct ItemCtx {
 // CR: the redo pass of points with a solve that WANDERED (more than kSafeSteps Newton steps): such a solve is done again from
 // its start with correctly rounded sin / cos (rvll_math.h, sincos_cr).  Where the reference's iteration wanders, where it stops
 // hangs on the last bit of sin / cos, and glibc's are correctly rounded nearly always: 90 of 20000 points at e = 0.95 .. 0.9925
-// were beyond 1e-10 of the oracle with the ~1.2-ulp kernels, 2 with this (profiles/r04_high_ecc_parity.txt).  It lives in the
+// were beyond 1e-10 of the reference arithmetic with the ~1.2-ulp kernels, 2 with this (profiles/r04_high_ecc_parity.txt).  It lives in the
 // redo pass because inside the first pass its mere presence cost every launch 3.7 % (63.3 -> 65.6 us: scalar registers).
 template <int PREC, bool FAILCHECK, bool EXTRAS = true, bool CR = false>
 __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx& cx, int pl, int j)
@@ -489,6 +489,137 @@ __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx&
         return div_fast(res * res, 2 * var);                                // rvmodel:80
     }
 #endif
+}
+
+// ---- the reduced-precision modes, two items per lane (RVLL_PREC_MIXED / RVLL_PREC_FP32; a.itmax > kF32Steps) -----------------
+// The items (plA, jA) and (plB, jB) side by side: the phase of each in fp64 as eval_item has it, the Newton iteration of the two
+// as one packed fp32 iteration (rvll_math.h, sincos_f32x2) that runs until every item of the WAVE has met the stop rule — a
+// scalar branch instead of a per-lane one; an item that has met it and takes further steps only comes closer to its root —
+// and at most kF32Steps steps: an item still moving then is solved in double from its start, as eval_item does it.  Not a
+// parity mode (tests/test_gpu_precision.py holds its distance from the fp64 path).
+template <int PREC, bool EXTRAS>
+__device__ __forceinline__ double pair_tail(const LoglikeArgs& a, const ItemCtx& cx, int pl, int j, double t, double y, double var, double rvm)
+{
+    if constexpr (EXTRAS) {
+        if (a.has_drift) {                                                  // rvmodel:242-271
+            const double* d = cx.dr + pl * 6;
+            const double tt = (t - d[4]) * (1.0 / 365.25);
+            const double t2 = tt * tt;
+            rvm += d[0] * tt + d[1] * t2 + d[2] * (t2 * tt) + d[3] * (t2 * t2);
+        }
+        for (int k = 0; k < a.nlin; ++k)                                    // rvmodel:210-212
+            rvm += cx.lin[pl * a.nlin + k] * a.linpar[(size_t)k * a.Ne + j];
+    }
+    const double res = y - rvm;                                             // rvmodel:215
+    if constexpr (PREC == RVLL_PREC_FP32) {
+        const float rf = (float)res, vf = (float)var;
+        return (double)div_f32(rf * rf, 2.0f * vf);
+    } else {
+        return div_fast(res * res, 2 * var);                                // rvmodel:80
+    }
+}
+
+// one solve in double from its start (the reduced-precision modes' way out of a wandering iteration); false: itmax reached
+__device__ __forceinline__ bool pair_solve_f64(const LoglikeArgs& a, const ItemCtx& cx, int pl, double M, double ec, double A, double Bq,
+                                               double C0, double& rv)
+{
+    double Ed = M, sd, cd, dd;
+    const SincosConsts kc = sincos_consts();
+    int steps = 0;
+    do {
+        sincos_any(Ed, sd, cd, kc);
+        const double f  = Ed - ec * sd - M;
+        const double fp = 1 - ec * cd;
+        const double En = Ed - div_exact(f, fp);
+        dd = En - Ed;
+        Ed = En;
+        ++steps;
+    } while (fabs(dd) > a.tol && steps < a.itmax);
+    if (steps > kSafeSteps) atomicOr(&cx.pflags[pl], RVLL_FLAG_WANDERED);
+    if (steps >= a.itmax) return false;
+    sincos_any(Ed, sd, cd, kc);
+    rv = div_fast(__builtin_fma(A, cd - ec, -(Bq * sd)), __builtin_fma(-ec, cd, 1.0)) + C0;
+    return true;
+}
+
+template <int PREC, bool EXTRAS>
+__device__ __forceinline__ void eval_item_pair(const LoglikeArgs& a, const ItemCtx& cx, int plA, int jA, int plB, int jB,
+                                               double& outA, double& outB)
+{
+    const double tA = a.t[jA], yA = a.y[jA], tB = a.t[jB], yB = a.y[jB];
+    const double2 ojA = *reinterpret_cast<const double2*>(cx.ins + (plA * a.Ni + a.inst[jA]) * 2);
+    const double2 ojB = *reinterpret_cast<const double2*>(cx.ins + (plB * a.Ni + a.inst[jB]) * 2);
+    double rvmA = 0. + ojA.x, rvmB = 0. + ojB.x;                            // rvmodel:187
+    const double varA = a.s2[jA] + ojA.y, varB = a.s2[jB] + ojB.y;         // rvmodel:189-192
+    const int Np = a.Np;
+    const f32x2 tolf = splat2((float)a.tol);
+    double ksumA = 0., ksumB = 0.;
+    for (int ip = 0; ip < Np; ++ip) {
+        const double* PA = cx.pp + (plA * Np + ip) * kPlanetFields;
+        const double* PB = cx.pp + (plB * Np + ip) * kPlanetFields;
+        const double2 a01 = *reinterpret_cast<const double2*>(PA), a23 = *reinterpret_cast<const double2*>(PA + 2);
+        const double2 b01 = *reinterpret_cast<const double2*>(PB), b23 = *reinterpret_cast<const double2*>(PB + 2);
+        const double2 a45 = *reinterpret_cast<const double2*>(PA + 4), b45 = *reinterpret_cast<const double2*>(PB + 4);
+        const double aC0 = PA[6], bC0 = PB[6];
+        const double MA = a01.x * (tA - a01.y) + a23.x;                     // rvmodel:459, in fp64
+        const double MB = b01.x * (tB - b01.y) + b23.x;
+        const f32x2 Mf = {reduce_2pi_to_f32(MA), reduce_2pi_to_f32(MB)};
+        const f32x2 ecf = {(float)a23.y, (float)b23.y};
+        f32x2 E = Mf, s, c, dE;
+        int steps = 0;
+        bool more;
+        auto newton = [&]() {
+            sincos_f32x2(E, s, c);
+            const f32x2 f  = E - ecf * s - Mf;
+            const f32x2 fp = splat2(1.0f) - ecf * c;
+            const f32x2 En = E - div_f32x2(f, fp);
+            dE = En - E;
+            E = En;
+            ++steps;
+            more = __builtin_amdgcn_ballot_w64(fabsf(dE.x) > tolf.x || fabsf(dE.y) > tolf.y) != 0;
+        };
+        do newton(); while (more && steps < kSafeSteps);
+        const f32x2 dE8 = dE;                 // every item settled: within tol; else the step at kSafeSteps (0.01 % of the waves)
+        if (__builtin_expect(more, 0)) { do newton(); while (more && steps < kF32Steps); }
+        const bool lateA = fabsf(dE8.x) > tolf.x, lateB = fabsf(dE8.y) > tolf.y;      // more than kSafeSteps steps: WANDERED
+        const bool movA = fabsf(dE.x) > tolf.x, movB = fabsf(dE.y) > tolf.y;
+        // the model term of both from the packed iterate: (s, c) are at the iterate before the last step, and that step is within
+        // tol for every item that goes on from here — rotated by it (h^3 / 6 <= 2e-10 dropped) instead of a third reduction
+        if (a.tol <= 1e-3) {
+            const f32x2 hh = splat2(0.5f) * dE * dE, s0 = s, c0 = c;
+            s = fma2(c0, dE, fma2(-s0, hh, s0));
+            c = fma2(-s0, dE, fma2(-c0, hh, c0));
+        } else {
+            sincos_f32x2(E, s, c);
+        }
+        const f32x2 den = fma2(-ecf, c, splat2(1.0f));
+        const f32x2 Af = {(float)a45.x, (float)b45.x}, Bf = {(float)a45.y, (float)b45.y}, Cf = {(float)aC0, (float)bC0};
+        const f32x2 num = fma2(Af, c - ecf, -(Bf * s));
+        const f32x2 rvf = div_f32x2(num, den) + Cf;
+        double rvA = (double)rvf.x, rvB = (double)rvf.y;
+        if (__builtin_expect(lateA || lateB || movA || movB, 0)) {
+            if (lateA && !movA) atomicOr(&cx.pflags[plA], RVLL_FLAG_WANDERED);
+            if (lateB && !movB) atomicOr(&cx.pflags[plB], RVLL_FLAG_WANDERED);
+            if (movA && !pair_solve_f64(a, cx, plA, MA, a23.y, a45.x, a45.y, aC0, rvA)) {
+                atomicMin(&cx.jfail[plA * Np + ip], jA);
+                atomicOr(&cx.anyfail[plA], 1);
+                atomicOr(cx.nfail, 1);
+                rvA = a45.x + aC0;
+            }
+            if (movB && !pair_solve_f64(a, cx, plB, MB, b23.y, b45.x, b45.y, bC0, rvB)) {
+                atomicMin(&cx.jfail[plB * Np + ip], jB);
+                atomicOr(&cx.anyfail[plB], 1);
+                atomicOr(cx.nfail, 1);
+                rvB = b45.x + bC0;
+            }
+        }
+        ksumA += rvA;                                                       // rvmodel:383
+        ksumB += rvB;
+    }
+    rvmA += ksumA;                                                          // rvmodel:199
+    rvmB += ksumB;
+    outA = pair_tail<PREC, EXTRAS>(a, cx, plA, jA, tA, yA, varA, rvmA);
+    outB = pair_tail<PREC, EXTRAS>(a, cx, plB, jB, tB, yB, varB, rvmB);
 }
 
 #ifndef RVLL_DECODE_INLINE
@@ -903,6 +1034,8 @@ __device__ __forceinline__ __attribute__((flatten)) void loglike_tile(const Logl
     // LDS windows are cut at point-local positions — whole points while a point fits the window, otherwise
     // every point by itself at multiples of CH — so each point's sum has one order whatever the tiling
     const int wpts = a.Ne <= a.CH ? a.CH / a.Ne : 0;
+    // reduced precision: two items per lane (eval_item_pair); a stop after fewer steps than its loop takes is left to eval_item
+    [[maybe_unused]] const bool pairs = PREC != RVLL_PREC_FP64 && a.itmax > kF32Steps;
     for (int base = 0, cend; base < nitems; base = cend) {
         cend = wpts ? min(base + wpts * a.Ne, nitems) : min(base + a.CH, (base / a.Ne + 1) * a.Ne);
         if constexpr (DYN) {
@@ -921,6 +1054,35 @@ __device__ __forceinline__ __attribute__((flatten)) void loglike_tile(const Logl
                 if (r * kWave >= cend) break;
 #endif
                 const int i = r * kWave + lane;
+                if constexpr (PREC != RVLL_PREC_FP64) {
+                    if (pairs) {
+                        // a second round of 64 items for the same lanes (none left: the first one twice, its second result dropped)
+                        int r2 = 0;
+                        if (lane == 0) r2 = atomicAdd(L.ticket, 1);
+                        r2 = __builtin_amdgcn_readfirstlane(r2);
+#ifndef RVLL_AB_NO_ROT
+                        r2 &= (1 << kTicketBits) - 1;
+                        bool has2 = r2 * kWave < cend;
+                        r2 += r0;
+                        if (r2 * kWave >= cend) r2 -= (cend + kWave - 1) >> 6;
+#else
+                        bool has2 = r2 * kWave < cend;
+#endif
+                        if (!has2) r2 = r;
+                        const int i2 = r2 * kWave + lane;
+                        int plA, jA, plB, jB;
+                        item_of(r * kWave, lane, a.Ne, plA, jA);
+                        item_of(r2 * kWave, lane, a.Ne, plB, jB);
+                        const bool okA = i < cend, okB = has2 && i2 < cend;
+                        if (!okA) { plA = 0; jA = 0; }
+                        if (!okB) { plB = plA; jB = jA; }
+                        double oA, oB;
+                        eval_item_pair<PREC, EXTRAS>(a, cx, plA, jA, plB, jB, oA, oB);
+                        if (okA) contrib[i] = oA;
+                        if (okB) contrib[i2] = oB;
+                        continue;
+                    }
+                }
                 if (i < cend) {
                     int pl, j;
                     item_of(r * kWave, lane, a.Ne, pl, j);
@@ -929,6 +1091,25 @@ __device__ __forceinline__ __attribute__((flatten)) void loglike_tile(const Logl
             }
             if constexpr (TRACE) { if (tid == 0) tr[4] = __builtin_amdgcn_s_memrealtime(); }
         } else {
+            bool done = false;
+            if constexpr (PREC != RVLL_PREC_FP64) {
+                if (pairs) {
+                    for (int i = base + tid; i < cend; i += 2 * NT) {
+                        const int i2 = i + NT;
+                        const bool wave2 = i2 - lane < cend, okB = i2 < cend;       // (the wave's second round exists; this lane's item in it)
+                        int plA, jA, plB, jB;
+                        item_of(i - lane, lane, a.Ne, plA, jA);
+                        item_of(wave2 ? i2 - lane : i - lane, lane, a.Ne, plB, jB);
+                        if (!okB) { plB = plA; jB = jA; }
+                        double oA, oB;
+                        eval_item_pair<PREC, EXTRAS>(a, cx, plA, jA, plB, jB, oA, oB);
+                        contrib[i - base] = oA;
+                        if (okB) contrib[i2 - base] = oB;
+                    }
+                    done = true;
+                }
+            }
+            if (!done)
             for (int i = base + tid; i < cend; i += NT) {
                 int pl, j;
                 item_of(i - lane, lane, a.Ne, pl, j);            // i - lane = base + 64 wave + k NT: the same for the whole wave

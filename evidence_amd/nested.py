@@ -13,6 +13,8 @@ UltraNest's region/step samplers on hard posteriors.
 from dataclasses import dataclass
 from typing import Callable, Optional
 
+import time
+
 import numpy as np
 
 from .settings import ultranest_defaults
@@ -28,6 +30,7 @@ class NestedResult:
     samples: np.ndarray          # dead + final live points (theta)
     logl: np.ndarray
     logwt: np.ndarray            # log posterior weights (normalised)
+    timing: dict = None          # resident live set: seconds in the order step, waiting for the live step, and the loop turns
 
 
 def _logaddexp_many(x):
@@ -224,9 +227,13 @@ def run_nested_slice(prior: Callable, loglike: Callable, ndim: int, nlive: Optio
     # at all — per iteration the log-L of the dying points comes down (the evidence sums need them), ranks go up
     device_order = live is not None and u is None and hasattr(live, "live_sort")
     top = float(np.max(logl)) if device_order else None
+    timing = {"order_s": 0.0, "step_wait_s": 0.0, "turns": 0}
     while it < max_iter and ncall < max_calls:
+        timing["turns"] += 1
+        t_turn = time.perf_counter()
         if device_order:
             dl, lstar, top = live.live_sort(kbatch)
+            timing["order_s"] += time.perf_counter() - t_turn
             ranks = rng.integers(0, nlive - kbatch, kbatch)          # (the draw the host order's alive[rng.integers(...)] makes)
             seed_it = int(rng.integers(0, 2 ** 62))
             pending = _helper().submit(live.live_step, None, kbatch, ranks, lstar, wrapped, nsteps, 200, seed_it)
@@ -236,6 +243,7 @@ def run_nested_slice(prior: Callable, loglike: Callable, ndim: int, nlive: Optio
             dead = order[:kbatch]
             lstar = logl[dead[-1]]
             dl = logl[dead]
+            timing["order_s"] += time.perf_counter() - t_turn
         if device_order:
             pass
         elif live is not None and u is None:
@@ -265,7 +273,9 @@ def run_nested_slice(prior: Callable, loglike: Callable, ndim: int, nlive: Optio
         dead_logl.append(dl); dead_logw.append(logw)
         it += kbatch
         if pending is not None:
+            t_wait = time.perf_counter()
             wl, used = pending.result()
+            timing["step_wait_s"] += time.perf_counter() - t_wait
             ncall += int(used)
             if device_order:
                 top = max(top, float(np.max(wl)))                     # the survivors' highest and the newcomers'
@@ -346,4 +356,4 @@ def run_nested_slice(prior: Callable, loglike: Callable, ndim: int, nlive: Optio
     all_logl = np.concatenate(dead_logl + [logl])
     all_logw = np.concatenate(dead_logw + [logw_live]) - logz_final
     return NestedResult(float(logz_final), float(np.sqrt(max(h, 0.0) / nlive)), it, ncall, float(h),
-                        all_theta, all_logl, all_logw)
+                        all_theta, all_logl, all_logw, timing)

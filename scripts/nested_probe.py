@@ -53,8 +53,9 @@ with GpuRVModel(w.fixedpardict, w.table, w.parnames, priordict=w.priordict()) as
             t1 = time.perf_counter()
             ns = run_nested_slice(None, None, m.ndim, live=Live, **kw)
             el = time.perf_counter() - t1
-            cur = (inside["calls"] / inside["s"], ns.ncall / el, ns.ncall, inside["slots"] / max(1, inside["calls"]), inside["rounds"], inside["it"], ns.logz)
+            cur = (inside["calls"] / inside["s"], ns.ncall / el, ns.ncall, inside["slots"] / max(1, inside["calls"]), inside["rounds"], inside["it"], ns.logz, ns.timing, el, inside["s"])
             if best is None or cur[0] > best[0]:
                 best = cur
         print(f"{name:28s}: inside the step {best[0]:.3e} calls/s, end to end {best[1]:.3e}  ({best[2]} calls, {best[3]:.3f} slots per call, "
-              f"{best[4]} rounds over {best[5]} iterations, ln Z so far {best[6]:.3f})", flush=True)
+              f"{best[4]} rounds over {best[5]} iterations, ln Z so far {best[6]:.3f}; per iteration: order {best[7]['order_s'] / best[7]['turns'] * 1e3:.3f} ms, "
+              f"live step {best[9] / best[5] * 1e3:.3f} ms, everything else incl. set-up and final downloads {(best[8] - best[9] - best[7]['order_s']) / best[5] * 1e3:.3f} ms)", flush=True)
