@@ -377,6 +377,124 @@ RVLL_HD void sincos_dd_kernel(DD r, double& s_out, double& c_out)
     c_out = c.hi;
 }
 
+// ---- the same values by a short route (the redo pass's sin / cos: one wave in a CU-wide launch held the launch for 2 us per
+// Newton step on the series above — a 300-step solve stretched a 1 ms launch to 1.4 ms) ----------------------------------------
+// r = k / 64 + h, |h| <= 2^-7: sin(k/64), cos(k/64) from a table in double-double, sin h and cos h - 1 by their series with the
+// leading terms in double-double, combined in double-double: 2^-68 of the value.  A result that close to a rounding boundary is
+// not decided by it (Ziv's test, about one value in 2^12): those go through the full series (sincos_dd_kernel).
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __constant__
+#endif
+static const double kSinCosTabDD[52][4] = {        // sin(k/64) (hi, lo), cos(k/64) (hi, lo), k = 0 .. 51
+    {0.0, 0.0, 1.0, 0.0},
+    {0.015624364224883372, -1.2650937552759816e-19, 0.9998779321710066, 3.216122229972341e-17},
+    {0.03124491398532608, -1.562781562225433e-18, 0.9995117584851364, -3.418806487972947e-17},
+    {0.04685783574813424, -2.3419368365610254e-18, 0.9989015683384429, -2.1425557800399754e-17},
+    {0.0624593178423802, -2.040259504585711e-18, 0.9980475107000991, 3.3232291674141346e-17},
+    {0.07804555138996731, -5.449443782005793e-18, 0.9969497940760287, -1.2467075728553626e-17},
+    {0.09361273123551289, 1.4628632005878733e-18, 0.9956086864580017, 3.312922430932991e-17},
+    {0.10915705687532236, 6.6284699502736666e-18, 0.9940245152582091, 1.3287985046260087e-17},
+    {0.12467473338522769, -2.925947496057858e-18, 0.992197667229329, 4.754870575189364e-17},
+    {0.1401619723470637, -9.946847113883478e-18, 0.9901285883701071, -4.589906353553811e-18},
+    {0.15561499277355603, 8.886053372342288e-18, 0.9878177838164719, 4.91917302237681e-17},
+    {0.17103002203139503, -9.954774726452923e-18, 0.9852658177182139, -4.925721262944555e-17},
+    {0.18640329676226988, 2.3493796901281573e-18, 0.9824733131012553, -3.919920375420088e-17},
+    {0.2017310638016388, 5.587232815460113e-18, 0.9794409517155483, 1.3108769521526758e-17},
+    {0.21700958109501015, 1.1170071073364376e-17, 0.9761694738686353, -7.850690609285027e-18},
+    {0.23223511861151147, -8.318080852687206e-18, 0.9726596782449127, 2.3920264546490165e-17},
+    {0.24740395925452294, -7.53102495590706e-18, 0.9689124217106447, 5.071436662403936e-17},
+    {0.2625123997691533, -2.2534597527902125e-17, 0.964928619104771, -3.0345542681018625e-18},
+    {0.2775567516463363, 1.7674070262791822e-17, 0.9607092430155619, -2.807827063516729e-17},
+    {0.29253334202332754, 7.516944930327352e-18, 0.9562553235431753, -3.148450868841629e-17},
+    {0.30743851458038085, 1.1004366442765296e-19, 0.9515679480481722, -3.8614834675674123e-17},
+    {0.3222686304333866, 2.093773358126606e-17, 0.9466482608860534, -3.911683334934152e-17},
+    {0.33702006902225307, 1.0312279860787216e-17, 0.9414974631278811, -4.8523830236797095e-18},
+    {0.3516892289948141, -2.5616208736069942e-17, 0.9361168122670553, -5.2350302039683216e-17},
+    {0.36627252908604757, -9.938814562106524e-18, 0.9305076219123143, 4.488760003328074e-18},
+    {0.38076640899239017, 2.1372528646211374e-17, 0.924671261467036, 5.5444125388034563e-17},
+    {0.39516733024093426, -1.9613487871414228e-17, 0.9186091557949183, -4.0564150104514996e-17},
+    {0.40947177705329507, -5.679403000091266e-18, 0.9123227848721178, 2.6349040211413332e-17},
+    {0.42367625720393803, -2.331800700068871e-17, 0.9058136834259364, 4.2864666490805214e-17},
+    {0.4377773028727551, 7.64345629962023e-18, 0.8990834405601384, 9.076951775075616e-18},
+    {0.4517714714916838, -8.234073942098903e-18, 0.8921336993669944, 2.3160655211380166e-17},
+    {0.46565534658516017, 1.459870391051426e-17, 0.8849661565261433, -7.690557775987357e-18},
+    {0.479425538604203, -5.103969860556013e-18, 0.8775825618903728, -4.2623149864279997e-17},
+    {0.49307868575392305, 5.605083973871755e-18, 0.8699847180584174, 1.657385110740923e-17},
+    {0.5066114548142574, -3.269413423618168e-17, 0.8621744799348805, 4.4132427578105805e-18},
+    {0.520020541953727, -3.983266745698455e-17, 0.8541537542773854, 5.420565102675286e-18},
+    {0.5333026735360201, 5.129318115032044e-17, 0.8459244992310679, 1.549506647350329e-17},
+    {0.5464546069192036, 8.399754840929507e-18, 0.8374887238505236, 4.3337026043948396e-17},
+    {0.5594731312473669, 1.575565514488728e-17, 0.8288484876093257, 1.1163935406617444e-17},
+    {0.5723550682345072, 2.6575872357215316e-17, 0.820005899897234, -3.912431748209128e-17},
+    {0.5850972729404622, -5.4883972461161805e-17, 0.8109631195052179, -3.091333486122179e-17},
+    {0.5976966345387015, 5.450323593054385e-17, 0.8017223540984184, 4.0134533311087014e-17},
+    {0.6101500770757914, -1.479826990758988e-17, 0.7922858596771786, -2.9049779312834576e-17},
+    {0.6224545602223437, -6.049035765709707e-18, 0.7826559400262728, -1.474071641211487e-17},
+    {0.6346070800152693, -3.4568582392624965e-17, 0.7728349461524715, 4.231014921891023e-17},
+    {0.6466046695911524, 4.567647714393289e-19, 0.7628252757105762, 1.6672995021546628e-17},
+    {0.6584443999105676, -3.7736386700306717e-17, 0.7526293724180665, -1.2970993013150526e-17},
+    {0.6701233804731629, 6.183536725574959e-18, 0.7422497254585013, -1.2339303604869521e-17},
+    {0.6816387600233341, 4.410467313197903e-17, 0.7316888688738209, -1.0475824306512768e-17},
+    {0.692987727246318, -5.3543290798909455e-17, 0.7209493809456964, 3.494986701478816e-17},
+    {0.7041675114545337, -3.94095700584825e-17, 0.7100338835660797, 1.505272211891291e-17},
+    {0.7151753832640076, -1.466099578328228e-17, 0.6989450415971057, -5.5261332036460915e-18},
+};
+
+// hi is the correctly rounded value of hi + lo + d for every |d| <= 2^-66 |hi|  (hi = RN(hi + lo))
+RVLL_HD bool dd_rounds_safely(double hi, double lo)
+{
+    const double err = __builtin_fabs(hi) * 1.3563e-20;             // 2^-66 and a little
+    return hi + (lo + err) == hi && hi + (lo - err) == hi;
+}
+
+// sin r, cos r for a double-double |r| <= pi/4 (+ a little); false: one of them is too close to a rounding boundary to call
+RVLL_HD bool sincos_dd_table(DD r, double& s_out, double& c_out)
+{
+    const double kf = __builtin_rint(r.hi * 64.0);
+    const int k = (int)kf;
+    const int ka = k < 0 ? -k : k;
+    const DD h = dd_two_sum(r.hi - kf * 0.015625, r.lo);            // (the subtraction is exact)
+    const double Sh = k < 0 ? -kSinCosTabDD[ka][0] : kSinCosTabDD[ka][0], Sl = k < 0 ? -kSinCosTabDD[ka][1] : kSinCosTabDD[ka][1];
+    const double Ch = kSinCosTabDD[ka][2], Cl = kSinCosTabDD[ka][3];
+    const DD q = dd_two_prod(h.hi, h.hi);
+    const double z = q.hi;
+    // sin h = h + p,  cos h - 1 = -q / 2 + w  (q = h^2 in double-double)
+    const double p = (h.hi * z) * __builtin_fma(z, __builtin_fma(z, __builtin_fma(z, 2.7557319223985893e-06, -1.984126984126984e-04),
+                                                                  8.333333333333333e-03), -1.6666666666666666e-01);
+    const double w = (z * z) * __builtin_fma(z, __builtin_fma(z, 2.48015873015873e-05, -1.3888888888888889e-03), 4.1666666666666664e-02);
+    const double sl = h.lo + p;                                     // sin h = (h.hi, sl)
+    const double cth = -0.5 * q.hi, ctl = __builtin_fma(-0.5, q.lo + 2.0 * h.hi * h.lo, w);      // cos h - 1 = (cth, ctl)
+    // sin r = S + (S (cos h - 1) + C sin h)
+    {
+        DD a = dd_two_prod(Ch, h.hi);
+        a.lo += Ch * sl + Cl * h.hi;
+        DD b = dd_two_prod(Sh, cth);
+        b.lo += Sh * ctl + Sl * cth;
+        DD u = dd_two_sum(a.hi, b.hi);
+        u.lo += a.lo + b.lo;
+        DD x = dd_two_sum(Sh, u.hi);
+        x.lo += u.lo + Sl;
+        x = dd_quick_sum(x.hi, x.lo);
+        s_out = x.hi;
+        if (!dd_rounds_safely(x.hi, x.lo)) return false;
+    }
+    // cos r = C + (C (cos h - 1) - S sin h)
+    {
+        DD a = dd_two_prod(-Sh, h.hi);
+        a.lo -= Sh * sl + Sl * h.hi;
+        DD b = dd_two_prod(Ch, cth);
+        b.lo += Ch * ctl + Cl * cth;
+        DD u = dd_two_sum(a.hi, b.hi);
+        u.lo += a.lo + b.lo;
+        DD x = dd_two_sum(Ch, u.hi);
+        x.lo += u.lo + Cl;
+        x = dd_quick_sum(x.hi, x.lo);
+        c_out = x.hi;
+        if (!dd_rounds_safely(x.hi, x.lo)) return false;
+    }
+    return true;
+}
+
 RVLL_HD void sincos_cr(double x, double& s_out, double& c_out)
 {
     if (!(__builtin_fabs(x) < __builtin_inf())) { s_out = c_out = __builtin_nan(""); return; }
@@ -384,7 +502,11 @@ RVLL_HD void sincos_cr(double x, double& s_out, double& c_out)
     uint32_t q;
     reduce_dd(x, r, q);
     double sr, cr;
+#ifdef RVLL_CR_SERIES_ONLY              // (measurement / test builds: every value through the full series)
     sincos_dd_kernel(r, sr, cr);
+#else
+    if (__builtin_expect(!sincos_dd_table(r, sr, cr), 0)) sincos_dd_kernel(r, sr, cr);
+#endif
     const double s = (q & 1u) ? cr : sr, c = (q & 1u) ? sr : cr;
     const double ss = (q & 2u) ? -s : s, cc = ((q + 1u) & 2u) ? -c : c;
     s_out = x < 0. ? -ss : ss;

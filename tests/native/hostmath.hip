@@ -7,6 +7,16 @@
 HM void hm_sincos(const double* x, long n, double* s, double* c) { for (long i = 0; i < n; ++i) rvll::sincos_f64(x[i], s[i], c[i]); }
 HM void hm_sincos_any(const double* x, long n, double* s, double* c) { for (long i = 0; i < n; ++i) rvll::sincos_any(x[i], s[i], c[i]); }
 HM void hm_sincos_cr(const double* x, long n, double* s, double* c) { for (long i = 0; i < n; ++i) rvll::sincos_cr(x[i], s[i], c[i]); }
+// the short route of sincos_cr by itself: ok[i] = 0 where it declines (too close to a rounding boundary)
+HM void hm_sincos_cr_table(const double* x, long n, double* s, double* c, int* ok) {
+    for (long i = 0; i < n; ++i) {
+        rvll::DD r; uint32_t q; double sr = 0., cr = 0.;
+        rvll::reduce_dd(x[i], r, q);
+        ok[i] = rvll::sincos_dd_table(r, sr, cr) ? 1 : 0;
+        const double a = (q & 1u) ? cr : sr, b = (q & 1u) ? sr : cr;
+        s[i] = ((q & 2u) ? -a : a) * (x[i] < 0 ? -1. : 1.);
+        c[i] = ((q + 1u) & 2u) ? -b : b;
+    } }
 // the long reduction by itself (any |x| >= 1), so that it can be checked where the short one is valid too
 HM void hm_sincos_long(const double* x, long n, double* s, double* c) {
     for (long i = 0; i < n; ++i) {

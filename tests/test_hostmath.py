@@ -173,6 +173,28 @@ def test_sincos_of_any_finite_double(hm):
     assert np.isnan(sb).all() and np.isnan(cb).all()
 
 
+def test_sincos_cr_short_route_is_correctly_rounded_where_it_answers(hm):
+    """The table route of sincos_cr (rvll_math.h, sincos_dd_table): wherever it answers, both values are THE nearest doubles
+    (mpmath at 200 bits), and it declines — Ziv's test; those go through the full series — for well under 1 % of the arguments."""
+    import mpmath
+    mpmath.mp.prec = 200
+    rng = np.random.default_rng(12)
+    x = np.concatenate([rng.uniform(-7, 7, 12000), rng.uniform(-0.8, 0.8, 6000), 10.0 ** rng.uniform(-30, 30, 3000) * rng.choice([-1, 1], 3000),
+                        rng.uniform(1e9, 2e22, 6000), np.arange(0, 52) / 64.0, np.arange(0, 52) / 64.0 + 2.0 ** -60,
+                        np.arange(1, 400) * (math.pi / 2), np.arange(1, 200) * (math.pi / 4)])
+    s, c, ok = np.empty_like(x), np.empty_like(x), np.empty(x.size, dtype=np.int32)
+    hm.hm_sincos_cr_table(x.ctypes.data_as(dp), C.c_long(x.size), s.ctypes.data_as(dp), c.ctypes.data_as(dp),
+                          ok.ctypes.data_as(C.POINTER(C.c_int)))
+    want_s = np.array([float(mpmath.sin(mpmath.mpf(float(v)))) for v in x])
+    want_c = np.array([float(mpmath.cos(mpmath.mpf(float(v)))) for v in x])
+    yes = ok != 0
+    assert yes.mean() > 0.99, float(yes.mean())
+    assert np.array_equal(s[yes], want_s[yes]) and np.array_equal(c[yes], want_c[yes])
+    # and the routine as a whole (short route, full series where it declines)
+    hm.hm_sincos_cr(x.ctypes.data_as(dp), C.c_long(x.size), s.ctypes.data_as(dp), c.ctypes.data_as(dp))
+    assert np.array_equal(s, want_s) and np.array_equal(c, want_c)
+
+
 def test_sincos_cr_is_correctly_rounded(hm):
     """sincos_cr (rvll_math.h, round 4): double-double reduction + Taylor series, rounded once — against mpmath at 200 bits on
     arguments from 1e-300 to 1e300, next to multiples of pi/2 included: every result is THE nearest double (0 ulp off); and
