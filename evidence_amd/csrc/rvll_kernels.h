@@ -138,8 +138,8 @@ hipError_t launch_slice_walk_rows(const LoglikeArgs& a, const WalkArgs& w, bool 
 // them), draws directions for the walkers that start a move and writes this round's candidates — one per listed walker, more
 // ahead while the round is below the chip's latency floor — into ONE compact array, prior transform included; then the batch
 // log-L kernel itself (the theta -> log-L tile, rvll_tile.h) evaluates that array, every workgroup an equal share of however many
-// candidates there are (the count stays on the device).  No host synchronisation between rounds; with two or more groups one
-// group's step rides in the launch of another group's tiles (rounds_kernel).  The random-number counters name the walker,
+// candidates there are (the count stays on the device).  No host synchronisation between rounds; the groups run on streams of
+// their own, one group's step beside another's tiles.  The random-number counters name the walker,
 // so end points, theta, log-L and the call count are those of slice_walk_kernel bit for bit (tests/test_gpu_walk.py).
 constexpr int kRoundsRing = 16;        // per-round counters (slots handed out, walkers listed) live in a ring of this many rounds
 struct RoundsArgs {
@@ -204,13 +204,7 @@ struct RoundsTiles {
 int rounds_walkers_per_block(int D, int spec_max, size_t lds_budget);
 size_t rounds_step_lds_bytes(int W, int D, int spec_max);
 int rounds_blocks_per_cu(size_t lds_bytes);
-// One launch (rvll_kernels.hip, rounds_kernel), `lds` bytes of dynamic LDS per workgroup: round r_step of the group *step (or
-// null) next to the log-L tiles of round r_ll of ANOTHER group — *ll with *out (or null) over `tiles` 256-thread workgroups of
-// at most a.PB points, equal shares of the count in out->ring_entry[0].  The two parts must not depend on each other.
-hipError_t launch_rounds(const RoundsArgs* step, int r_step, const LoglikeArgs* ll, const RoundsTiles* out, int tiles, int r_ll,
-                         size_t lds, hipStream_t stream);
-
-// the two parts as launches of their own (a stream per group)
+// a group's round: two launches on the group's stream
 hipError_t launch_rounds_step(const RoundsArgs& g, int round, hipStream_t stream);
 hipError_t launch_rounds_tiles(const LoglikeArgs& a, const RoundsTiles& out, int tiles, int round, hipStream_t stream);
 // the tiles of a round alone, in the CU-wide form: `tiles` 1024-thread workgroups of at most a.PB points (a.CH >= a.PB * a.Ne)

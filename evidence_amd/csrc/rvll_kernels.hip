@@ -59,51 +59,6 @@ void loglike_kernel(const LoglikeArgs a)                                // form 
     loglike_tile<PREC, FUSED, false, kThreads, false, EXTRAS>(a, smem, p0, npts);
 }
 
-// One launch of the walk in its rounds form (rvll_rounds.h, rvll_walk_host.hip): the STEP of one group of walkers (workgroups
-// [0, n_step): dispatched first, they wait on memory most of their short life) next to the LOG-L TILES of another group (the
-// rest of the grid) — the tile form of loglike_kernel (theta -> log-L: the step made the prior transform) on a batch whose
-// size stays on the device, every tile an equal share
-// (<= a.PB points) of the ring entry's count; every result also goes to its walker's record, where the group's next step
-// finds it without first having to look up where its candidates went.  Why one kernel: launched one after the other in one
-// stream the two cannot overlap, and on streams of their own the groups fall into lock step — both step (the chip idle for
-// 20 - 30 us), then both run their tiles (profiles/r04_rounds_timeline.txt: 99 us per round of 16384 candidates against
-// 70 us of tile work).  Inside one launch the step's workgroups take their slots first and the tiles fill the chip around
-// them; the host sizes the tiles so that both parts are resident together.  Either part may be empty.
-// The kernel lives in this unit, beside the other instantiations of the tile, because hipcc's inlining — and with it the
-// register allocation of the item loop — depends on how many call sites the tile's routines have in a unit: in a unit of
-// its own the same tile spilled 28 VGPRs into scratch; here it allocates like loglike_kernel (profiles/r04_kernel_resources.txt).
-template <int PREC, bool EXTRAS>
-__global__ __launch_bounds__(kThreads, 4) __attribute__((flatten))
-void rounds_kernel(const LoglikeArgs a, const RoundsArgs g, const RoundsTiles o, const int n_step, const int r_step, const int r)
-{
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    if ((int)blockIdx.x < n_step) {
-        // a step is a short chain of latencies beside tiles whose waves would otherwise get three of every four issue slots
-        // of the SIMD they share (arbitration is by priority, then age): 34 us a step against 13 us alone
-        __builtin_amdgcn_s_setprio(3);
-        rounds_step(g, r_step, (int)blockIdx.x, smem);
-        return;
-    }
-    const int tile = (int)blockIdx.x - n_step, tiles = (int)gridDim.x - n_step;
-    if (o.progress && tile == 0 && threadIdx.x == 0)     // (round, walkers listed) for the host, which keeps the queue a few rounds deep
-        __hip_atomic_store(o.progress, ((unsigned long long)(unsigned)(r + 1) << 32) | (unsigned)o.ring_entry[1], __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_SYSTEM);
-    const int B = __builtin_amdgcn_readfirstlane(o.ring_entry[0]);
-    const int per = (B + tiles - 1) / tiles;
-    const long long p0 = (long long)tile * per;
-    const int npts = (int)min((long long)per, (long long)B - p0);
-    if (npts <= 0) return;
-    loglike_tile<PREC, kFusedNone, false, kThreads, false, EXTRAS>(a, smem, p0, npts);
-    // every result also to its walker's record (the tile's last barrier is behind us: its sums are in LDS)
-    const TileLds L = tile_views(a, smem);
-    for (int pl = threadIdx.x; pl < npts; pl += kThreads) {
-        int f;
-        const double v = tile_point_result(a, L, pl, f);
-        const int ow = o.owner[p0 + pl];
-        o.wres_logl[ow] = v;
-        o.wres_flags[ow] = f;
-    }
-}
 
 __global__ __launch_bounds__(kThreads)
 void rounds_dirs_kernel(const RoundsDirs g)
@@ -522,7 +477,7 @@ hipError_t launch_loglike_cu(const LoglikeArgs& a, int grid, hipStream_t stream)
     return hipGetLastError();
 }
 
-// ---- the walk in its rounds form: host side of rounds_kernel
+// ---- the walk in its rounds form: host side
 // walkers per workgroup of the step: as many as `lds_budget` bytes hold (the step shares its launch, and with it the size of
 // the dynamic LDS, with the log-L tiles: four workgroups are to fit a compute unit), one lane of a wave each at most
 int rounds_walkers_per_block(int D, int spec_max, size_t lds_budget)
@@ -534,53 +489,14 @@ int rounds_walkers_per_block(int D, int spec_max, size_t lds_budget)
 
 size_t rounds_step_lds_bytes(int W, int D, int spec_max) { return step_lds_bytes(W, D, spec_max); }
 
-// workgroups of rounds_kernel a compute unit holds with `lds` bytes of dynamic LDS each (0: the query failed)
+// workgroups of the tiles kernel a compute unit holds with `lds` bytes of dynamic LDS each (0: the query failed)
 int rounds_blocks_per_cu(size_t lds)
 {
     int occ = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (rounds_kernel<RVLL_PREC_FP64, false>), kThreads, lds) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (rounds_tiles_kernel<RVLL_PREC_FP64, false>), kThreads, lds) != hipSuccess) return 0;
     return occ;
 }
 
-hipError_t launch_rounds(const RoundsArgs* step, int r_step, const LoglikeArgs* ll, const RoundsTiles* out, int tiles, int r_ll,
-                         size_t lds, hipStream_t stream)
-{
-    int n_step = 0;
-    RoundsArgs g{};
-    LoglikeArgs a{};
-    RoundsTiles o{};
-    if (step && step->K > 0) {
-        g = *step;
-        if (g.W < 1 || g.W > kWave || g.D < 1 || g.spec_max < 1 || g.C < g.K || g.c_free > g.C || g.c_free < 1 || r_step < 0 ||
-            g.nsteps >= (1 << 18) || g.max_rounds < 1 || g.max_rounds > 4096 || (long long)g.K * g.spec_max >= (1LL << 31) ||
-            !g.priors || !g.light_dims || (g.n_heavy > 0 && !g.heavy_dims) || g.n_heavy > g.D || !g.theta_c[0] || !g.theta_c[1] || !g.wdef || !g.wflag ||
-            !g.dirs || !g.dirnext || step_lds_bytes(g.W, g.D, g.spec_max) > lds)
-            return hipErrorInvalidValue;
-        n_step = (int)((g.K + g.W - 1) / g.W);
-    }
-    if (ll && tiles > 0) {
-        a = *ll;
-        if (!out || !a.theta || a.cube || !a.flags || !a.logL || a.PB < 1 ||
-            !out->ring_entry || !out->owner || !out->wres_logl || !out->wres_flags || loglike_lds_bytes(a) > lds)
-            return hipErrorInvalidValue;
-        o = *out;
-    } else {
-        tiles = 0;
-    }
-    if (n_step + tiles < 1) return hipSuccess;
-    if (lds > 64 * 1024) return hipErrorInvalidValue;
-    const bool lean = tiles == 0 || (!a.has_drift && a.nlin == 0);
-    const dim3 grid((unsigned)(n_step + tiles)), block(kThreads);
-    switch (tiles ? a.precision : RVLL_PREC_FP64) {
-    case RVLL_PREC_MIXED: hipLaunchKernelGGL((rounds_kernel<RVLL_PREC_MIXED, true>), grid, block, lds, stream, a, g, o, n_step, r_step, r_ll); break;
-    case RVLL_PREC_FP32:  hipLaunchKernelGGL((rounds_kernel<RVLL_PREC_FP32, true>), grid, block, lds, stream, a, g, o, n_step, r_step, r_ll); break;
-    default:
-        if (lean) hipLaunchKernelGGL((rounds_kernel<RVLL_PREC_FP64, false>), grid, block, lds, stream, a, g, o, n_step, r_step, r_ll);
-        else      hipLaunchKernelGGL((rounds_kernel<RVLL_PREC_FP64, true>), grid, block, lds, stream, a, g, o, n_step, r_step, r_ll);
-        break;
-    }
-    return hipGetLastError();
-}
 
 hipError_t launch_rounds_dirs(const RoundsDirs& g, int max_blocks, hipStream_t stream)
 {

@@ -69,15 +69,21 @@ void moments_sum_kernel(const double* u, const int32_t* idx, long long n, int D,
     }
 }
 
-// out[d] = (sum over blocks, in block order) * scale
+// out[d] = (sum over blocks) * scale: four threads a column, each a quarter of the blocks in block order, the quarters added in
+// order — a fixed order for a given width.  (One thread a column walked 128 dependent loads: 9.5 us a call, two calls a step.)
+constexpr int kFoldCols = kThreads / 4;
 __global__ __launch_bounds__(kThreads)
 void moments_fold_kernel(const double* part, int width, double scale, double* out)
 {
-    for (int d = threadIdx.x; d < width; d += kThreads) {
-        double s = 0.;
-        for (int b = 0; b < kMomBlocks; ++b) s += part[(long long)b * width + d];
-        out[d] = s * scale;
-    }
+    __shared__ double q[4][kFoldCols];
+    const int c = threadIdx.x % kFoldCols, k = threadIdx.x / kFoldCols;
+    const int d = blockIdx.x * kFoldCols + c;
+    double s = 0.;
+    if (d < width)
+        for (int b = k * (kMomBlocks / 4); b < (k + 1) * (kMomBlocks / 4); ++b) s += part[(long long)b * width + d];
+    q[k][c] = s;
+    __syncthreads();
+    if (k == 0 && d < width) out[d] = ((q[0][c] + q[1][c]) + (q[2][c] + q[3][c])) * scale;
 }
 
 // partial sums of the centred products (u_j - m_j)(u_l - m_l): thread p one (j, l) pair, rows as above — staged through LDS
@@ -189,9 +195,9 @@ hipError_t launch_moments(const double* u, const int32_t* idx, long long n, int 
     if (n <= 0 || D <= 0) return hipErrorInvalidValue;
     double* part = scratch;
     hipLaunchKernelGGL(moments_sum_kernel, dim3(kMomBlocks), dim3(kThreads), 0, st, u, idx, n, D, part);
-    hipLaunchKernelGGL(moments_fold_kernel, dim3(1), dim3(kThreads), 0, st, part, D, 1.0 / (double)n, mean);
+    hipLaunchKernelGGL(moments_fold_kernel, dim3((D + kFoldCols - 1) / kFoldCols), dim3(kThreads), 0, st, part, D, 1.0 / (double)n, mean);
     hipLaunchKernelGGL(moments_cov_kernel, dim3(kMomBlocks), dim3(kThreads), sizeof(double) * ((size_t)kCovRows * D + D), st, u, idx, n, D, mean, part);
-    hipLaunchKernelGGL(moments_fold_kernel, dim3(1), dim3(kThreads), 0, st, part, D * D, 1.0 / (double)(n > 1 ? n - 1 : 1), cov);
+    hipLaunchKernelGGL(moments_fold_kernel, dim3((D * D + kFoldCols - 1) / kFoldCols), dim3(kThreads), 0, st, part, D * D, 1.0 / (double)(n > 1 ? n - 1 : 1), cov);
     return hipGetLastError();
 }
 

@@ -3,7 +3,7 @@
 // per new point, circular omega / ml0 — evidence/ultranest/__init__.py:159-175): accept / shrink on the previous round's
 // results, directions for the walkers that start a move, this round's candidates (compacted: one array, one count on the
 // device), prior transform included; and the directions of all moves, made ahead of time.  Device code, included by
-// rvll_kernels.hip (kernels rounds_dirs_kernel, rounds_step_kernel, rounds_kernel).
+// rvll_kernels.hip (kernels rounds_dirs_kernel, rounds_step_kernel; rounds_tiles_kernel evaluates the candidates).
 // Same arithmetic per walker as slice_walk_kernel (rvll_walk.hip), operation for operation — the counters of the random
 // numbers name the walker and the move, never where or when it is evaluated — so the results are the same bits.
 #pragma once

@@ -1042,31 +1042,34 @@ __device__ __forceinline__ __attribute__((flatten)) void loglike_tile(const Logl
             // one window (host-checked): wave rounds of 64 consecutive items, drawn from the ticket counter
             for (;;) {
                 int r = 0;
-                if (lane == 0) r = atomicAdd(L.ticket, 1);
+                // (reduced precision, item pairs: two tickets at once — which two rounds share their lanes is then fixed, and
+                // with it every item's wave-wide step count: the same launch gives the same bits)
+                [[maybe_unused]] int r2 = 0;
+                if constexpr (PREC != RVLL_PREC_FP64) {
+                    if (lane == 0) r = atomicAdd(L.ticket, pairs ? 2 : 1);
+                } else {
+                    if (lane == 0) r = atomicAdd(L.ticket, 1);
+                }
                 r = __builtin_amdgcn_readfirstlane(r);
 #ifndef RVLL_AB_NO_ROT                      // (measurement builds only: scripts/build_variants.sh)
                 const int r0 = (r >> kTicketBits) & kTicketRoundMask;      // where the decode step said to start
                 r &= (1 << kTicketBits) - 1;
                 if (r * kWave >= cend) break;
+                r2 = r + 1;
                 r += r0;
                 if (r * kWave >= cend) r -= (cend + kWave - 1) >> 6;
 #else
                 if (r * kWave >= cend) break;
+                r2 = r + 1;
 #endif
                 const int i = r * kWave + lane;
                 if constexpr (PREC != RVLL_PREC_FP64) {
                     if (pairs) {
-                        // a second round of 64 items for the same lanes (none left: the first one twice, its second result dropped)
-                        int r2 = 0;
-                        if (lane == 0) r2 = atomicAdd(L.ticket, 1);
-                        r2 = __builtin_amdgcn_readfirstlane(r2);
+                        // the second round of 64 items for the same lanes (none left: the first one twice, its second result dropped)
+                        const bool has2 = r2 * kWave < cend;
 #ifndef RVLL_AB_NO_ROT
-                        r2 &= (1 << kTicketBits) - 1;
-                        bool has2 = r2 * kWave < cend;
                         r2 += r0;
                         if (r2 * kWave >= cend) r2 -= (cend + kWave - 1) >> 6;
-#else
-                        bool has2 = r2 * kWave < cend;
 #endif
                         if (!has2) r2 = r;
                         const int i2 = r2 * kWave + lane;

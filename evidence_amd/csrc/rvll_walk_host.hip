@@ -59,8 +59,8 @@ bool rounds_wanted(int64_t K)
 }
 
 // The K rows of d_walk_u / d_walk_theta / d_walk_logl (chol, wrapped uploaded) walked in rounds: G groups of rows; a group's
-// round = its step, then the batch log-L tiles over its candidates — and every launch carries the tiles of one group next to
-// the step of another (rvll_kernels.hip, rounds_kernel), all in lane 0's stream.  The host only keeps the queue a few rounds
+// round = its step, then the batch log-L tiles over its candidates, the groups on streams of their own (rvll_kernels.hip,
+// rounds_step_kernel / rounds_tiles_kernel).  The host only keeps the queue a few rounds
 // deep: the tiles publish (round, walkers listed) to a word per group in mapped pinned memory; a group is done when a round
 // listed nobody (what is already queued behind it finds nothing to do).  Leaves the end points in the walk buffers, moves
 // completed in d_walk_steps (a walker the slim prior stage deferred: < nsteps), and synchronises the stream.
@@ -84,20 +84,19 @@ int walk_rounds(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t
     // (measured, 16384 walkers: 1300: 1.50, 2600: 1.61, 4000: 1.68, 6000: 1.72, 8000: 1.71e8 calls/s).  Scaled by the epochs.
     long long c_free = std::max<long long>(256, (long long)h->n_cu * 4608 / std::max(1, h->Ne));
     if (const char* e = getenv("RVLL_ROUNDS_FREE")) c_free = std::max(1, atoi(e));
-    // How the rounds are issued (RVLL_ROUNDS_MODE / RVLL_ROUNDS_FORM, measurement switches):
-    //   fused    one stream; every launch = one group's tiles (256-thread form) + another group's step (rounds_kernel)
-    //   streams  a stream per group; a group's round = a step launch, then a tiles launch (256-thread form or CU-wide)
-    const char* menv = getenv("RVLL_ROUNDS_MODE");
+    // How the rounds are issued: a stream per group; a group's round = a step launch, then a tiles launch (256-thread form, or
+    // CU-wide: RVLL_ROUNDS_FORM=cu, a measurement switch).  (A third structure — one stream, every launch one group's tiles next
+    // to another group's step in one kernel — was measured slower, 1.2e8 against 1.7e8 calls/s, its kernel spilled, and it is
+    // gone: profiles/r04_rounds_sweep.txt.)
     const char* fenv = getenv("RVLL_ROUNDS_FORM");
-    const bool fused = menv ? !strcmp(menv, "fused") : false;
-    const bool cu_form = !fused && fenv && !strcmp(fenv, "cu");
+    const bool cu_form = fenv && !strcmp(fenv, "cu");
     rvll::LoglikeArgs a;
     long long per = (K + G - 1) / G;
     int rc = build_args(h, nullptr, nullptr, nullptr, std::max(per, c_free), &a);
     if (rc) return rc;
     // the step's walkers per workgroup: within what leaves four workgroups a compute unit when it shares its launches (and with
     // them the size of the dynamic LDS) with the tiles, up to a wave's lanes otherwise
-    const size_t lds_budget = fused ? std::max<size_t>(rvll::loglike_lds_bytes(a), 36 * 1024) : (size_t)60 * 1024;
+    const size_t lds_budget = (size_t)60 * 1024;
     int W = rvll::rounds_walkers_per_block(D, spec, lds_budget);
     if (W < 1) return RVLL_E_UNSUPPORTED;
     if (const char* e = getenv("RVLL_ROUNDS_W")) W = std::max(1, std::min(W, atoi(e)));      // measurement switch
@@ -106,7 +105,6 @@ int walk_rounds(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t
     const long long C = std::max(per, c_free), nblk = per / W;
     c_free = std::min(c_free, C);
     if (C >= (1LL << 30) || per * spec >= (1LL << 31)) return RVLL_E_UNSUPPORTED;
-    const size_t step_lds = rvll::rounds_step_lds_bytes(W, D, spec);
     auto window = [&](int pb) { return (std::min(h->chunk_items, std::max(rvll::kThreads, pb * h->Ne)) + 1) & ~1; };
     if (cu_form) {
         // one CU-wide tile per compute unit: every contribution of the tile resident in LDS
@@ -119,7 +117,7 @@ int walk_rounds(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t
     } else {
         // 256-thread tiles sized to the wave slots the chip has left beside one group's step workgroups (but never smaller
         // than the cost model's choice): a tile that waits for a step's slot ends its launch a step's latency late
-        const size_t lds0 = fused ? std::max(rvll::loglike_lds_bytes(a), step_lds) : rvll::loglike_lds_bytes(a);
+        const size_t lds0 = rvll::loglike_lds_bytes(a);
         const int occ = rvll::rounds_blocks_per_cu(lds0);
         const long long room = (long long)std::max(1, occ) * h->n_cu - (G > 1 ? nblk : 0);
         const long long want = room > 0 ? (C + room - 1) / room : a.PB;
@@ -135,12 +133,12 @@ int walk_rounds(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t
             if (rvll::loglike_lds_bytes(b) <= 60 * 1024) a = b;
         }
     }
-    const size_t lds = fused ? std::max(rvll::loglike_lds_bytes(a), step_lds) : rvll::loglike_lds_bytes(a);
+    const size_t lds = rvll::loglike_lds_bytes(a);
     const int tiles = (int)((C + a.PB - 1) / a.PB);
-    a.cr_redo = 0;                 // (the walk's tiles leave the exact redo of wandering solves to walk_core: see there)
+    a.cr_redo = getenv("RVLL_WALK_CR") ? atoi(getenv("RVLL_WALK_CR")) : 0;                 // (the walk's tiles leave the exact redo of wandering solves to walk_core: see there)
     if (getenv("RVLL_WALK_GEOM_DUMP"))
         fprintf(stderr, "[rounds] K=%lld G=%d %s %s per=%lld C=%lld c_free=%lld W=%d step blocks=%lld PB=%d tiles=%d lds=%zu spec=%d\n", (long long)K, G,
-                fused ? "fused" : "streams", cu_form ? "cu" : "tile", per, C, c_free, W, nblk, a.PB, tiles, lds, spec);
+                "streams", cu_form ? "cu" : "tile", per, C, c_free, W, nblk, a.PB, tiles, lds, spec);
     // arena: per group  doubles | 64-bit words | walker words (int4) | ints
     const size_t n_dbl = 2 * (size_t)per * D + 2 * (size_t)per + 2 * (size_t)C * D + 2 * (size_t)per * spec + (size_t)C;
     const size_t n_ll = 2 * (size_t)nblk + rvll::kRoundsRing;
@@ -239,7 +237,7 @@ int walk_rounds(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t
     // is its step when they are equal, its tiles otherwise)
     std::vector<long long> n_step((size_t)G, 0), n_tile((size_t)G, 0);
     std::vector<char> done((size_t)G, 0);
-    int ndone = 0, status = RVLL_OK, turn = 0;
+    int ndone = 0, status = RVLL_OK;
     auto last_progress = steady_clock::now();
     const auto t_walk0 = steady_clock::now();
     long long launch_ns = 0, n_launch = 0;
@@ -248,11 +246,11 @@ int walk_rounds(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t
     // not keep the groups out of lock step: 1.45 against 1.51e8 calls/s)
     std::vector<hipStream_t> gs((size_t)G, h->compute);
     const char* cenv = getenv("RVLL_ROUNDS_CHAIN");
-    const bool chain = !fused && G > 1 && cenv && atoi(cenv) != 0;       // measured: 1.57 against 1.71e8 calls/s unchained
+    const bool chain = G > 1 && cenv && atoi(cenv) != 0;       // measured: 1.57 against 1.71e8 calls/s unchained
     if (chain)
         for (int g = 0; g < G; ++g)
             if (!h->ev_chain[g]) HIP_TRY(hipEventCreateWithFlags(&h->ev_chain[g], hipEventDisableTiming));
-    if (!fused && G > 1) {
+    if (G > 1) {
         const char* penv = getenv("RVLL_ROUNDS_PRIO");
         const bool prio = penv && atoi(penv) != 0;
         int lo_p = 0, hi_p = 0;
@@ -279,44 +277,7 @@ int walk_rounds(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t
     while (ndone < G && status == RVLL_OK) {
         unsigned long long sum = 0;
         bool any = false;
-        if (fused) {
-            // the next launch: the tiles of the first group (from `turn` on) that has a step waiting to be evaluated, next to
-            // the step of the first OTHER group that needs one.  A pair is launched as a pair: while one of the two is at its
-            // queue depth nothing goes out — launching the other alone would put every later launch out of step, one part each
-            // (the groups become eligible one at a time as their rounds start: measured, 7.4e7 calls/s against 1.4e8).
-            int g_tile = -1, g_step = -1;
-            bool blocked = false;
-            for (int k = 0; k < G; ++k) {
-                const int g = (turn + k) % G;
-                if (done[(size_t)g]) continue;
-                const unsigned long long p = __atomic_load_n(&h->pin_rounds[g], __ATOMIC_ACQUIRE);
-                const long long pub = (long long)(p >> 32);          // rounds whose tiles have started
-                sum += p;
-                if (pub > 0 && (unsigned)p == 0u) { done[(size_t)g] = 1; ++ndone; continue; }
-                const bool full = n_tile[(size_t)g] - pub >= depth;
-                if (n_step[(size_t)g] > n_tile[(size_t)g]) { if (g_tile < 0) { g_tile = g; blocked |= full; } }
-                else if (g_step < 0) { g_step = g; blocked |= full; }
-            }
-            if (blocked) g_tile = g_step = -1;
-            if (g_step >= 0 && n_step[(size_t)g_step] >= r_max) {
-                status = report_error(RVLL_E_HIP, "rounds walk: group %d did not finish in %lld rounds", g_step, r_max);
-                break;
-            }
-            if (g_tile >= 0 || g_step >= 0) {
-                const int rs = g_step >= 0 ? (int)n_step[(size_t)g_step] : 0, rt = g_tile >= 0 ? (int)n_tile[(size_t)g_tile] : 0;
-                if (g_tile >= 0) {
-                    ta[(size_t)g_tile].ring_entry = ga[(size_t)g_tile].ring + 2 * (rt % rvll::kRoundsRing);
-                    la[(size_t)g_tile].theta = ga[(size_t)g_tile].theta_c[rt & 1];
-                }
-                const hipError_t e = rvll::launch_rounds(g_step >= 0 ? &ga[(size_t)g_step] : nullptr, rs, g_tile >= 0 ? &la[(size_t)g_tile] : nullptr,
-                                                         g_tile >= 0 ? &ta[(size_t)g_tile] : nullptr, tiles, rt, lds, h->compute);
-                if (e != hipSuccess) { status = report_error(RVLL_E_HIP, "rounds walk launch failed: %s", hipGetErrorString(e)); break; }
-                if (g_step >= 0) n_step[(size_t)g_step] += 1;
-                if (g_tile >= 0) n_tile[(size_t)g_tile] += 1;
-                turn = (turn + 1) % G;
-                any = true;
-            }
-        } else if (chain) {
+        if (chain) {
             // (RVLL_ROUNDS_CHAIN=1, a measurement switch.)  Left to themselves the groups fall into lock step: all step together
             // (the chip idle for a step's 20 us), then all run their tiles together.  Here the steps are CHAINED: group g's step
             // of a round waits (an event, on the device) for group g - 1's step of that round — it starts when g - 1's tiles do
@@ -379,7 +340,7 @@ int walk_rounds(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t
         }
         std::this_thread::yield();
     }
-    for (int g = 0; g < (fused ? 1 : G); ++g) {
+    for (int g = 0; g < G; ++g) {
         const hipError_t e = hipStreamSynchronize(gs[(size_t)g]);
         if (e != hipSuccess && status == RVLL_OK) status = report_error(RVLL_E_HIP, "rounds walk: %s", hipGetErrorString(e));
     }
@@ -443,7 +404,7 @@ int walk_core(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t m
         // candidates nearly always has one).  So the walk's tiles evaluate such candidates with the ordinary sin / cos — the
         // accept decision cannot tell the two values apart unless they straddle lstar, 1e-9 of |log-L| apart — and report which
         // walkers END on one (w.wflag); their log-L is put right below, by the batch kernel, which carries the redo.
-        a->cr_redo = 0;
+        a->cr_redo = getenv("RVLL_WALK_CR") ? atoi(getenv("RVLL_WALK_CR")) : 0;      // (measurement switch)
         auto window = [&](int pb) {                    // the tile's contribution window also holds 3 PB D doubles of the walk
             int ch = std::min(h->chunk_items, std::max(rvll::kThreads, pb * h->Ne));
             ch = std::max(ch, 3 * pb * a->D);

@@ -40,12 +40,19 @@ def test_cu_form_is_bit_identical_to_tiles(gpu_required, cfg, n):
 
 
 @pytest.mark.parametrize("precision", ["mixed", "fp32"])
-def test_cu_form_bit_identical_in_reduced_precision(gpu_required, precision):
+def test_cu_form_in_reduced_precision_same_values_to_float_rounding(gpu_required, precision):
     w = make_workload(3)
     theta = w.sample_theta(5000, seed=11)
     with GpuRVModel(w.fixedpardict, w.table, w.parnames, precision=precision) as m:
         got = _both(m, theta)
-    assert np.array_equal(got["tile"][0], got["cu"][0])
+        again = _both(m, theta)
+    # Round 4: the reduced-precision modes run their Newton iteration wave-wide (two items a lane, until every item of the wave
+    # has met the stop rule: rvll_tile.h, eval_item_pair), so an item may take a step or two more than it needs, depending on
+    # its neighbours in the wave: the same launch gives the same bits, another tiling the same values to a few float ulps of
+    # the model.  (The parity mode, fp64, is bit-identical across forms: the tests around this one.)
+    for form in ("tile", "cu"):
+        assert np.array_equal(got[form][0], again[form][0])
+    assert np.max(np.abs(got["tile"][0] - got["cu"][0]) / np.abs(got["tile"][0])) <= 3e-7
 
 
 def test_cu_form_itmax_and_invalid_orbits(gpu_required):

@@ -46,16 +46,20 @@ def test_walk_invariants(gpu_required, cfg, k):
 @pytest.mark.parametrize("precision", ["mixed", "fp32"])
 def test_walk_and_scalar_server_in_the_reduced_precision_modes(gpu_required, precision):
     """The walk kernel and the scalar-call server are instantiated per precision mode: same invariants, judged
-    against the batch path of the SAME mode (bit for bit)."""
+    against the batch path of the SAME mode — theta bit for bit (the prior transform is fp64 in every mode), log-L to float
+    rounding of the model: the reduced modes' Newton loop runs wave-wide since round 4 and an item's step count goes by its
+    wave (tests/test_gpu_forms.py)."""
     w = make_workload(3)
     with GpuRVModel(w.fixedpardict, w.table, w.parnames, priordict=w.priordict(), precision=precision) as m:
         cube, theta, logl, lstar, chol = _start(m, w, 2000, seed=4)
         c2, t2, l2, n = m.slice_walk(cube, theta, logl, lstar, chol, wrapped_params(m.parnames), nsteps=6, seed=2)
         th_chk, ll_chk = m.prior_loglike_batch(c2)
-        assert (l2 > lstar).all() and np.array_equal(th_chk, t2) and np.array_equal(ll_chk, l2) and n >= 6 * len(cube)
+        assert (l2 > lstar).all() and np.array_equal(th_chk, t2) and n >= 6 * len(cube)
+        assert np.max(np.abs(ll_chk - l2) / np.abs(l2)) <= 3e-7
         want = m.log_likelihood_batch(t2[:32])
         m.scalar_server(True)
-        assert np.array_equal(np.array([m.log_likelihood(x) for x in t2[:32]]), want)
+        got = np.array([m.log_likelihood(x) for x in t2[:32]])
+        assert np.max(np.abs(got - want) / np.abs(want)) <= 3e-7
 
 
 def test_walk_gives_up_a_move_after_max_rounds_and_accepts_no_wrapping(gpu_required):
@@ -287,14 +291,14 @@ def test_rounds_form_is_the_single_kernel_walk(gpu_required, monkeypatch):
     over the group's compacted candidates; walker state resident in HBM (csrc/rvll_rounds.h) — instead of one kernel that
     keeps its walkers in LDS.  It is what walks of 6144 .. 24576 rows take by default (where it was measured faster,
     profiles/r04_rounds_sizes.txt); RVLL_WALK_ROUNDS=1 / 0 forces / forbids it.  How the walkers are grouped, how the rounds
-    are issued (a stream per group, chained or not; one stream with one group's step inside another's tile launch), which
+    are issued (a stream per group, chained or not), which
     form the tiles take, how many candidates a walker gets ahead, how deep the host keeps the queues: none of it shows in
     the results, which are those of the single-kernel walk bit for bit — end points, theta, log-L, the number of likelihood
     calls — with and without walkers deferred to the full-solver pass on the way."""
     knobs = ("RVLL_WALK_ROUNDS", "RVLL_ROUNDS_GROUPS", "RVLL_ROUNDS_FREE", "RVLL_ROUNDS_DEPTH", "RVLL_WALK_SPEC", "RVLL_ROUNDS_FORM",
              "RVLL_ROUNDS_MODE", "RVLL_ROUNDS_CHAIN", "RVLL_ROUNDS_PRIO", "RVLL_ROUNDS_W", "RVLL_ROUNDS_PB")
     variants = [{}, {"RVLL_ROUNDS_GROUPS": "1"}, {"RVLL_ROUNDS_GROUPS": "2", "RVLL_ROUNDS_FORM": "cu"}, {"RVLL_ROUNDS_GROUPS": "4", "RVLL_WALK_SPEC": "1"},
-                {"RVLL_ROUNDS_MODE": "fused", "RVLL_ROUNDS_GROUPS": "2"}, {"RVLL_ROUNDS_CHAIN": "1"}, {"RVLL_ROUNDS_PRIO": "1", "RVLL_ROUNDS_W": "16"},
+                {"RVLL_ROUNDS_GROUPS": "2"}, {"RVLL_ROUNDS_CHAIN": "1"}, {"RVLL_ROUNDS_PRIO": "1", "RVLL_ROUNDS_W": "16"},
                 {"RVLL_WALK_SPEC": "16", "RVLL_ROUNDS_FREE": "100000"}, {"RVLL_ROUNDS_FREE": "1", "RVLL_ROUNDS_DEPTH": "1"},
                 {"RVLL_ROUNDS_DEPTH": "9", "RVLL_ROUNDS_PB": "3"}]
     for cfg, k, nsteps in ((3, 5000, 9), (3, 131, 21), (1, 40, 7), (5, 600, 5)):
