@@ -390,6 +390,21 @@ def run_extras(out, model, w, theta, B, with_cpu, device_index=0):
         # ... and the log-L kernel by itself on exactly those points (theta is resident from the call above): the
         # headline batch is another draw, and a launch's time depends on which points it gets
         out["loglike_alone_on_those_points_evals_per_s"] = timed(B, lambda: model.dev_loglike(B), 50, fill=False)
+        # Round 4: a Kepler solve that wanders (e >= 0.97, tens to hundreds of Newton steps) is redone with correctly rounded
+        # sin / cos by default (rvll_set_wander_exact; <= 1e-10 of the reference there too) — a serial chain of ~0.8 us steps
+        # in one lane that the launch waits for.  Whether a batch holds such a point goes by the draw (this one: see
+        # points_wandered; the headline batch holds none): the same three figures with the redo switched off.
+        try:
+            flags = model.dev_download(B, logl=False, flags=True)[2]
+            model.set_wander_exact(False)
+            out["prior_draw_with_exact_redo_off"] = {
+                "points_wandered_in_this_draw": int(np.count_nonzero(flags & 4)),
+                "loglike_alone_on_those_points_evals_per_s": timed(B, lambda: model.dev_loglike(B), 50, fill=False),
+                "prior_plus_loglike_one_launch_evals_per_s": timed(B, lambda: model.dev_prior_loglike(B), 50),
+                "prior_plus_loglike_evals_per_s": timed(B, lambda: (model.dev_prior(B), model.dev_loglike(B)), 50),
+                "note": "rvll_set_wander_exact(0): flagged points (RVLL_FLAG_WANDERED) then agree with the reference to ~1e-9 instead of 1e-10"}
+        finally:
+            model.set_wander_exact(True)
         # a sampler's proposal round: a small batch, where a launch is a large part of the step — the prior transform
         # in the log-L tile's staging step (one launch) against prior kernels + log-L kernel; a sync per step, as a
         # sampler that looks at every result would have
@@ -683,6 +698,22 @@ def sharded_config_steps(make, rank, ranks, shards, steps, step_of, kick=None, v
                        "kepler_solves_per_s": ranks * B * n / el * len(model.layout.planets) * w.table.n_epochs}
                 if prec == "fp64":
                     ref_logl = logl
+                    # the same steps without the exact redo of wandering solves (round 4, rvll_set_wander_exact: on by default):
+                    # what a launch waits for when its shard holds such a point (every rank makes the same steps: collectives)
+                    flags = model.dev_download(B, logl=False, flags=True)[2]
+                    model.set_wander_exact(False)
+                    for _ in range(3):
+                        step()
+                    model.dev_sync()
+                    if kick:
+                        kick()
+                    t0 = time.perf_counter()
+                    for _ in range(n):
+                        step()
+                    model.dev_sync()
+                    el_off = finish(time.perf_counter() - t0)
+                    model.set_wander_exact(True)
+                    rec["exact_redo_off"] = {"ms_per_step": el_off / n * 1e3, "points_wandered_in_this_shard": int(np.count_nonzero(flags & 4))}
                 else:
                     err = np.abs(logl - ref_logl) / np.maximum(np.abs(ref_logl), 1e-300)
                     rec.update(max_rel_err_vs_fp64=float(err.max()), median_rel_err_vs_fp64=float(np.median(err)),

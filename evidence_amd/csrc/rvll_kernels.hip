@@ -372,6 +372,15 @@ void debug_eval_kernel(int op, const double* x, const double* y, long long n, do
         case 12: r = wave_sum(a); break;                 // lane 0 of every wave: the shuffle tree
         case 13: r = wave_sum_lane0(a); break;           //                        the same tree without the LDS crossbar
         case 14: r = ndtri_cephes(a); break;
+        case 20: sincos_cr(a, s, c); r = s; break;       // the redo pass's correctly rounded pair (tests/test_gpu_math.py)
+        case 21: sincos_cr(a, s, c); r = c; break;
+        // latency chains, 1000 dependent evaluations a lane (scripts/cr_latency_probe.py): what one Newton step of a wandering
+        // solve waits for — the whole routine, its reduction, its two kernels, the ordinary pair
+        case 15: { double v = a; for (int k = 0; k < 1000; ++k) { sincos_cr(v, s, c); v = v * 1.0000001 + s * 1e-3; } r = v; break; }
+        case 16: { double v = a; for (int k = 0; k < 1000; ++k) { DD rr; uint32_t q; reduce_dd(v, rr, q); v = v * 1.0000001 + rr.hi * 1e-3 + (double)q; } r = v; break; }
+        case 17: { double v = a; for (int k = 0; k < 1000; ++k) { sincos_dd_table(DD{v, 1e-20}, s, c); v = 0.7 * s + 1e-3 * c; } r = v; break; }
+        case 18: { double v = a; for (int k = 0; k < 1000; ++k) { sincos_dd_kernel(DD{v, 1e-20}, s, c); v = 0.7 * s + 1e-3 * c; } r = v; break; }
+        case 19: { double v = a; for (int k = 0; k < 1000; ++k) { sincos_any(v, s, c); v = v * 1.0000001 + s * 1e-3; } r = v; break; }
         default: r = NAN; break;
         }
         out[i] = r;

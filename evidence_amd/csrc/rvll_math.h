@@ -316,6 +316,27 @@ RVLL_HD void reduce_dd(double x, DD& r, uint32_t& q)
 {
     const double ax = __builtin_fabs(x);
     if (ax <= 0.78539816339744828) { r = {ax, 0.}; q = 0; return; }
+#ifndef RVLL_CR_LONG_REDUCTION_ONLY       // (measurement / test builds: every argument through the integer reduction)
+    if (ax < 70368744177664.0) {
+        // below 2^46 (k is then the right multiple to 2^-7: |r| <= 0.794, inside the table's range): k pi/2 taken off in double-double — pi/2 in four words, every product with its error term (FMA); the
+        // absolute error is ~2^-108, so a result below 2^-20 (an argument that close to a multiple of pi/2: one in 2^19) is
+        // left to the integer reduction below, which keeps 106 bits of whatever is left.  A third of its latency, and a
+        // wandering Newton iteration spends most of its steps here (|E| grows by at most 1 / (1 - e) ~ 130 a step).
+        const double kf = __builtin_rint(ax * 6.36619772367581382433e-01);
+        const double P1 = 1.5707963267948966, P2 = 6.123233995736766e-17, P3 = -1.4973849048591698e-33, P4 = 5.562271104316826e-50;
+        const DD p1 = dd_two_prod(kf, P1), p2 = dd_two_prod(kf, P2);
+        const double t = ax - p1.hi;                                    // exact (p1.hi is within a factor two of ax)
+        const DD a = dd_two_sum(t, -p1.lo);
+        const DD b = dd_two_sum(a.hi, -p2.hi);
+        const double tail = ((a.lo + b.lo) - p2.lo) - __builtin_fma(kf, P3, kf * P4);
+        const DD s = dd_quick_sum(b.hi, tail);
+        if (__builtin_fabs(s.hi) >= 9.5367431640625e-07) {
+            r = s;
+            q = (uint32_t)(int)(kf - 4.0 * __builtin_floor(kf * 0.25));
+            return;
+        }
+    }
+#endif
     const uint64_t bits = as_u64(x) & 0x7fffffffffffffffull;
     const int ex = (int)(bits >> 52) - 1075;
     const uint64_t M = (bits & 0x000fffffffffffffull) | 0x0010000000000000ull;
@@ -452,7 +473,8 @@ RVLL_HD bool sincos_dd_table(DD r, double& s_out, double& c_out)
 {
     const double kf = __builtin_rint(r.hi * 64.0);
     const int k = (int)kf;
-    const int ka = k < 0 ? -k : k;
+    int ka = k < 0 ? -k : k;
+    if (ka > 51) ka = 51;                                           // (|r| <= pi/4 + 2^-12 by the reductions: 50 at most)
     const DD h = dd_two_sum(r.hi - kf * 0.015625, r.lo);            // (the subtraction is exact)
     const double Sh = k < 0 ? -kSinCosTabDD[ka][0] : kSinCosTabDD[ka][0], Sl = k < 0 ? -kSinCosTabDD[ka][1] : kSinCosTabDD[ka][1];
     const double Ch = kSinCosTabDD[ka][2], Cl = kSinCosTabDD[ka][3];

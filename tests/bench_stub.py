@@ -42,6 +42,9 @@ class StubModel:
     def set_points_per_block(self, pb):
         pass
 
+    def set_wander_exact(self, on=True):
+        pass
+
     def dev_upload_theta(self, theta):
         self._theta = np.array(theta, dtype=np.float64)
 

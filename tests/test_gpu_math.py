@@ -103,3 +103,20 @@ def test_lane0_tree_without_lds_crossbar_is_the_shuffle_tree(dev):
         v[:, :off] = v[:, :off] + v[:, off:2 * off]
     assert np.array_equal(shfl, v[:, 0])
     assert np.array_equal(fast, v[:, 0])
+
+
+def test_device_sincos_cr_is_correctly_rounded(dev):
+    """The redo pass's sin / cos pair ON THE DEVICE (debug_eval 20 / 21: rvll_math.h sincos_cr — double-double reduction, table
+    route with Ziv's test, full series where it declines) against mpmath at 200 bits: every value THE nearest double, from
+    1e-300 to 1e300, next to multiples of pi/2 included (the host compilation of the same header: tests/test_hostmath.py)."""
+    import math
+    import mpmath
+    mpmath.mp.prec = 200
+    rng = np.random.default_rng(21)
+    x = np.concatenate([rng.uniform(-20, 20, 4000), 10.0 ** rng.uniform(-300, 300, 1000) * rng.choice([-1, 1], 1000),
+                        rng.uniform(1e9, 2e22, 3000), np.arange(1, 300) * (math.pi / 2), np.arange(0, 52) / 64.0,
+                        np.array([0.0, 0.7853981633974483, -0.7853981633974483, 1e22, 2.0 ** 50, 2.0 ** 1023])])
+    s, c = dev.debug_eval(20, x), dev.debug_eval(21, x)
+    want_s = np.array([float(mpmath.sin(mpmath.mpf(float(v)))) for v in x])
+    want_c = np.array([float(mpmath.cos(mpmath.mpf(float(v)))) for v in x])
+    assert np.array_equal(s, want_s) and np.array_equal(c, want_c)

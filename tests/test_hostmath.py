@@ -181,7 +181,9 @@ def test_sincos_cr_short_route_is_correctly_rounded_where_it_answers(hm):
     rng = np.random.default_rng(12)
     x = np.concatenate([rng.uniform(-7, 7, 12000), rng.uniform(-0.8, 0.8, 6000), 10.0 ** rng.uniform(-30, 30, 3000) * rng.choice([-1, 1], 3000),
                         rng.uniform(1e9, 2e22, 6000), np.arange(0, 52) / 64.0, np.arange(0, 52) / 64.0 + 2.0 ** -60,
-                        np.arange(1, 400) * (math.pi / 2), np.arange(1, 200) * (math.pi / 4)])
+                        np.arange(1, 400) * (math.pi / 2), np.arange(1, 200) * (math.pi / 4),
+                        rng.uniform(2.0 ** 45, 2.0 ** 47, 3000), rng.uniform(2.0 ** 30, 2.0 ** 46, 3000),                               # either side of where the reduction changes routes
+                        (rng.integers(1, 2 ** 45, 3000) * (math.pi / 2)).astype(float)])        # next to large multiples of pi/2
     s, c, ok = np.empty_like(x), np.empty_like(x), np.empty(x.size, dtype=np.int32)
     hm.hm_sincos_cr_table(x.ctypes.data_as(dp), C.c_long(x.size), s.ctypes.data_as(dp), c.ctypes.data_as(dp),
                           ok.ctypes.data_as(C.POINTER(C.c_int)))
