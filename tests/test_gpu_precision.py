@@ -17,7 +17,7 @@ def _run(w, theta, precision):
 
 
 # (max, median) of the relative log-L error against the fp64 path, per config and mode: at most 5x what was measured on
-# the MI355X for these very samples (max 1.2e-7 / 1.4e-7 / 9.2e-8 for cfg2 / 3 / 5, medians 2.0e-10 ..
+# the MI355X for these very samples (profiles/DESIGN_history_r1_r3.md §4 table; max 1.2e-7 / 1.4e-7 / 9.2e-8 for cfg2 / 3 / 5, medians 2.0e-10 ..
 # 3.5e-8), so a regression by an order of magnitude fails
 BOUNDS = {
     (2, "mixed"): (6e-7, 1.0e-9), (2, "fp32"): (6e-7, 1.8e-7),
