@@ -92,6 +92,7 @@ int walk_rounds(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t
     const bool cu_form = fenv && !strcmp(fenv, "cu");
     rvll::LoglikeArgs a;
     long long per = (K + G - 1) / G;
+    if (const char* e = getenv("RVLL_ROUNDS_PER")) per = std::max<long long>(1, std::min<long long>(K, atoll(e)));   // measurement switch: rows a group (the last group takes the rest: unequal groups)
     int rc = build_args(h, nullptr, nullptr, nullptr, std::max(per, c_free), &a);
     if (rc) return rc;
     // the step's walkers per workgroup: within what leaves four workgroups a compute unit when it shares its launches (and with

@@ -11,7 +11,7 @@ from evidence_amd.callbacks import wrapped_params
 from evidence_amd.nested import run_nested_slice
 from evidence_amd.synthetic import make_workload
 
-SWITCHES = ("RVLL_WALK_ROUNDS", "RVLL_WALK_CR", "RVLL_ROUNDS_GROUPS", "RVLL_ROUNDS_FREE", "RVLL_ROUNDS_DEPTH", "RVLL_WALK_SPEC", "RVLL_ROUNDS_W", "RVLL_ROUNDS_PB", "RVLL_ROUNDS_MODE", "RVLL_ROUNDS_FORM", "RVLL_ROUNDS_PRIO", "RVLL_ROUNDS_CHAIN")
+SWITCHES = ("RVLL_WALK_ROUNDS", "RVLL_ROUNDS_PER", "RVLL_WALK_CR", "RVLL_ROUNDS_GROUPS", "RVLL_ROUNDS_FREE", "RVLL_ROUNDS_DEPTH", "RVLL_WALK_SPEC", "RVLL_ROUNDS_W", "RVLL_ROUNDS_PB", "RVLL_ROUNDS_MODE", "RVLL_ROUNDS_FORM", "RVLL_ROUNDS_PRIO", "RVLL_ROUNDS_CHAIN")
 settings = [("single-kernel", {"RVLL_WALK_ROUNDS": "0"}), ("rounds default", {})]
 for arg in sys.argv[1:]:
     name, _, rest = arg.partition("=")
