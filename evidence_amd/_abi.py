@@ -198,11 +198,12 @@ def load():
     global HW_QUEUES_NOTE
     hip_already = _hip_runtime_loaded()
     chosen = "GPU_MAX_HW_QUEUES" in os.environ
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-    HW_QUEUES_NOTE = {"GPU_MAX_HW_QUEUES": os.environ["GPU_MAX_HW_QUEUES"], "set_by": "the caller" if chosen else "evidence_amd (default 8)",
+    if not os.environ.get("RVLL_KEEP_HW_QUEUES"):            # (measurement switch: leave the variable alone, here and in librvll's constructor)
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    HW_QUEUES_NOTE = {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES", "unset"), "set_by": "the caller" if chosen else "evidence_amd (default 8)",
                       "hip_runtime_loaded_before_librvll": hip_already,
                       "in_effect": "unknown: the HIP runtime was already up and reads the variable only when it starts" if hip_already and not chosen
-                                   else os.environ["GPU_MAX_HW_QUEUES"]}
+                                   else os.environ.get("GPU_MAX_HW_QUEUES", "unset (runtime default: 4)")}
     try:
         lib = C.CDLL(str(path))
     except OSError as exc:

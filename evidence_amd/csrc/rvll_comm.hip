@@ -112,6 +112,21 @@ int rvll_comm_unique_id(unsigned char id[RVLL_COMM_ID_BYTES])
     return RVLL_OK;
 }
 
+// The streamed host batches want eight hardware queues (include/rvll.h, rvll_runtime_info): a library should not leave its fast
+// path to an environment variable its caller has to know about, so librvll asks for them itself when it is
+// loaded — unless the caller has chosen — which is before the process's first HIP call whenever librvll is what brings the HIP
+// runtime in.  rvll_runtime_info says who set it.
+namespace {
+bool g_hwq_by_library = false;
+__attribute__((constructor)) void rvll_default_hw_queues()
+{
+    if (!getenv("GPU_MAX_HW_QUEUES") && !getenv("RVLL_KEEP_HW_QUEUES")) {
+        setenv("GPU_MAX_HW_QUEUES", "8", 0);
+        g_hwq_by_library = true;
+    }
+}
+}  // namespace
+
 int rvll_runtime_info(char* buf, int32_t buflen)
 {
     if (!buf || buflen < 1) return report_error(RVLL_E_INVALID, "bad buffer");
@@ -123,10 +138,11 @@ int rvll_runtime_info(char* buf, int32_t buflen)
     const char* q = getenv("GPU_MAX_HW_QUEUES");
     snprintf(buf, (size_t)buflen,
              "{\"hip_runtime_version\": %d, \"hip_driver_version\": %d, \"libamdhip64\": \"%s\", "
-             "\"librccl\": \"%s\", \"rccl_version\": %d, \"librvll\": \"%s\", \"gpu_max_hw_queues_env\": \"%s\"}",
+             "\"librccl\": \"%s\", \"rccl_version\": %d, \"librvll\": \"%s\", \"gpu_max_hw_queues_env\": \"%s\", \"gpu_max_hw_queues_set_by\": \"%s\"}",
              hip_rt, hip_drv, lib_path_of(reinterpret_cast<const void*>(&hipGetDeviceCount)).c_str(),
              g_rccl.lib ? g_rccl_path.c_str() : "not loaded", g_rccl_version,
-             lib_path_of(reinterpret_cast<const void*>(&rvll_runtime_info)).c_str(), q ? q : "unset (runtime default: 4)");
+             lib_path_of(reinterpret_cast<const void*>(&rvll_runtime_info)).c_str(), q ? q : "unset (runtime default: 4)",
+             g_hwq_by_library ? "librvll when it was loaded" : (q ? "the caller's environment" : "nobody"));
     return RVLL_OK;
 }
 

@@ -376,12 +376,13 @@ int rvll_allgather_host(rvll_handle* h, const double* mine, int64_t n_local, dou
 /* Which libraries this process actually runs on, as a JSON object: HIP runtime version and path of libamdhip64,
  * path and version of the librccl that was loaded (RVLL_RCCL_PATH, else the one next to that libamdhip64, else
  * /opt/rocm/lib, else by soname), path of librvll itself, and GPU_MAX_HW_QUEUES as the environment has it.
- * A NOTE FOR C CALLERS on that variable: the HIP runtime maps a process's streams onto that many hardware queues (default
- * 4) and reads it once, when it starts.  A handle has seven streams; with four queues a copy stream of the streamed host
- * batches (rvll_prior_loglike_batch from 24 MB of rows on) can share the kernels' queue, and a 262144-row call then takes
- * 3.3 ms instead of 2.0 ms.  Nothing else depends on it (results never do).  Export GPU_MAX_HW_QUEUES=8 before the process
- * makes its first HIP call if you use those batches; the Python binding does so at load time unless the variable is set,
- * and reports whether that can have taken effect (GpuRVModel.runtime_info()["hw_queues"]).                              */
+ * ON THAT VARIABLE: the HIP runtime maps a process's streams onto that many hardware queues (default 4) and reads it once, when
+ * it starts.  A handle has seven streams; with four queues a copy stream of the streamed host batches
+ * (rvll_prior_loglike_batch from 24 MB of rows on) can share the kernels' queue, and a 262144-row call then takes 4.0 ms
+ * instead of 2.85 ms (profiles/r04_hw_queues.txt).  Nothing else depends on it (results never do).  librvll therefore asks
+ * for 8 ITSELF when it is loaded, unless the variable is set already (or RVLL_KEEP_HW_QUEUES is): that is in time whenever
+ * librvll is what brings the HIP runtime into the process; a caller that has made HIP calls before loading librvll exports
+ * GPU_MAX_HW_QUEUES=8 itself.  "gpu_max_hw_queues_set_by" in the JSON says which of the two happened.                   */
 int rvll_runtime_info(char* buf, int32_t buflen);
 /* One multi-GPU step is rvll_dev_loglike(B_local) followed by rvll_allgather_logl(B_local): every rank's
  * per-shard log-L (the buffer the kernel just wrote) is all-gathered on the device, rank-major, so that every

@@ -116,3 +116,22 @@ def test_oracle_is_not_imported_by_the_product():
     for path in (REPO / "evidence_amd" / "csrc").iterdir():
         if path.suffix in (".hip", ".h", ".cpp"):
             assert "oracle" not in path.read_text().lower(), path
+
+
+def test_the_library_asks_for_its_hardware_queues_itself_unless_the_caller_has_chosen():
+    """the streamed host batches' fast path must not hang on an environment variable the caller has to know
+    about.  librvll's load-time constructor (csrc/rvll_comm.hip) sets GPU_MAX_HW_QUEUES=8 in the process's C environment when
+    it is unset, and leaves a caller's choice alone.  (Fresh processes: the variable is read by the HIP runtime when it starts.)"""
+    import subprocess
+    import sys
+    from evidence_amd import _abi
+    code = ("import ctypes, os, sys\n"
+            "os.environ.pop('GPU_MAX_HW_QUEUES', None)\n"
+            "if sys.argv[2] != '-': os.environ['GPU_MAX_HW_QUEUES'] = sys.argv[2]\n"
+            "ctypes.CDLL(sys.argv[1])\n"
+            "libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p\n"
+            "print((libc.getenv(b'GPU_MAX_HW_QUEUES') or b'unset').decode())\n")
+    for chosen, want in (("-", "8"), ("2", "2")):
+        out = subprocess.run([sys.executable, "-c", code, str(_abi.LIB_PATH), chosen], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        assert out.stdout.strip() == want, (chosen, out.stdout, out.stderr)
