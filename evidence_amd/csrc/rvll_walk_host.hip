@@ -243,6 +243,8 @@ int walk_rounds(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t
     const auto t_walk0 = steady_clock::now();
     long long launch_ns = 0, n_launch = 0;
     unsigned long long seen_sum = 0;
+    const bool listed_dump = getenv("RVLL_ROUNDS_LISTED_DUMP") != nullptr;      // diagnostics: group 0's walkers listed, round by round (as the host saw them)
+    std::vector<unsigned long long> listed_seen;
     // The groups' streams: the handle's lanes (RVLL_ROUNDS_PRIO=1, a measurement switch: streams of DIFFERENT priorities — it did
     // not keep the groups out of lock step: 1.45 against 1.51e8 calls/s)
     std::vector<hipStream_t> gs((size_t)G, h->compute);
@@ -320,6 +322,7 @@ int walk_rounds(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t
                 const unsigned long long p = __atomic_load_n(&h->pin_rounds[g], __ATOMIC_ACQUIRE);
                 const long long pub = (long long)(p >> 32);
                 sum += p;
+                if (listed_dump && g == 0 && (listed_seen.empty() || listed_seen.back() != p)) listed_seen.push_back(p);
                 if (pub > 0 && (unsigned)p == 0u) { done[(size_t)g] = 1; ++ndone; continue; }
                 if (n_tile[(size_t)g] - pub >= depth) continue;
                 if (n_tile[(size_t)g] >= r_max) { status = report_error(RVLL_E_HIP, "rounds walk: group %d did not finish in %lld rounds", g, r_max); break; }
@@ -344,6 +347,22 @@ int walk_rounds(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t
     for (int g = 0; g < G; ++g) {
         const hipError_t e = hipStreamSynchronize(gs[(size_t)g]);
         if (e != hipSuccess && status == RVLL_OK) status = report_error(RVLL_E_HIP, "rounds walk: %s", hipGetErrorString(e));
+    }
+    if (listed_dump && !listed_seen.empty()) {
+        long long below[4] = {0, 0, 0, 0};
+        const long long full = ga[0].K;
+        for (unsigned long long p : listed_seen) {
+            const long long l = (long long)(unsigned)p;
+            if (l * 2 < full) ++below[0];
+            if (l * 4 < full) ++below[1];
+            if (l * 10 < full) ++below[2];
+            if (l * 50 < full) ++below[3];
+        }
+        fprintf(stderr, "[rounds listed] group 0: %lld walkers, %lld rounds to the end (%zu seen by the host); rounds with fewer than 1/2, 1/4, 1/10, 1/50 of the walkers listed: %lld %lld %lld %lld (of the seen);",
+                full, (long long)(listed_seen.back() >> 32), listed_seen.size(), below[0], below[1], below[2], below[3]);
+        for (size_t k = 0; k < listed_seen.size(); k += std::max<size_t>(1, listed_seen.size() / 24))
+            fprintf(stderr, " r%lld:%u", (long long)(listed_seen[k] >> 32), (unsigned)listed_seen[k]);
+        fprintf(stderr, "\n");
     }
     if (getenv("RVLL_WALK_GEOM_DUMP"))
         fprintf(stderr, "[rounds host] %lld launches, %.2f us each inside the launch calls, walk %.2f ms\n", n_launch, n_launch ? launch_ns / 1e3 / n_launch : 0.,
