@@ -231,9 +231,12 @@ int walk_rounds(rvll_handle* h, int64_t K, double lstar, int32_t nsteps, int32_t
             ga[0].stamps = d_stamps;  ga[0].stamp_rounds = stamp_rounds;
         }
     }
-    const long long r_max = (long long)nsteps * max_rounds + 2;       // every round consumes a candidate of every listed walker
     int depth = 4;                                                      // rounds queued beyond the last one seen starting
     if (const char* e = getenv("RVLL_ROUNDS_DEPTH")) depth = std::max(1, atoi(e));
+    // Every round consumes a candidate of every listed walker, so a group has listed nobody by round nsteps * max_rounds + 1 — and the
+    // host may have queued `depth` rounds beyond the last one it has seen start (without that allowance a walk with max_rounds = 1
+    // was refused while its last rounds were still in the queue: found by scripts/walk_soak.py).
+    const long long r_max = (long long)nsteps * max_rounds + 2 + depth;
     // per group: rounds whose step / whose tiles have been launched (tiles <= step <= tiles + 1: the next thing a group needs
     // is its step when they are equal, its tiles otherwise)
     std::vector<long long> n_step((size_t)G, 0), n_tile((size_t)G, 0);

@@ -78,3 +78,21 @@ def test_reduced_precision_does_not_fall_apart_at_the_eccentricity_clamp(gpu_req
     assert err[ecc <= 0.95].max() <= 1e-4, float(err[ecc <= 0.95].max())
     assert err.max() <= 0.1, float(err.max())       # at the clamp 1 / f' ~ 100 multiplies a float's 1e-7 on E into 1e-2 on log-L
     assert np.median(err) <= 1e-5, float(np.median(err))
+
+
+@pytest.mark.parametrize("precision", ["mixed", "fp32"])
+def test_item_pairs_and_single_items_agree_to_float_rounding(gpu_required, precision):
+    """Round 4: with the reference's itmax (10000) the reduced-precision modes evaluate two items a lane with a wave-wide stop rule
+    (rvll_tile.h, eval_item_pair); an itmax of 16 or less keeps the single-item path (its per-item stop counts against itmax).
+    Same points, both paths: the same values to a few float ulps of the model wherever no solve comes near sixteen steps, and
+    the same flags."""
+    case = golden.config_case(3)
+    theta = np.tile(case.theta, (30, 1))
+    out = {}
+    for itmax in (16, 10000):
+        with GpuRVModel(case.fixed, case.table, case.parnames, precision=precision, itmax=itmax) as m:
+            out[itmax] = m.log_likelihood_batch(theta, return_flags=True)
+    assert np.array_equal(out[16][1], out[10000][1])
+    assert (out[16][1] == 0).all()
+    assert golden.rel_err(out[16][0], out[10000][0]).max() <= 3e-7
+    assert golden.rel_err(out[10000][0], np.tile(case.logL, 30)).max() <= 1e-6

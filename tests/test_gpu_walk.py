@@ -345,6 +345,30 @@ def test_rounds_form_is_the_single_kernel_walk(gpu_required, monkeypatch):
         assert key not in __import__("os").environ
 
 
+def test_rounds_form_with_few_candidates_a_move(gpu_required, monkeypatch):
+    """max_rounds = 1 and 3 (a move is given up after that many candidates) through the rounds form at its default queue depth and at
+    deeper ones: the host keeps several rounds queued beyond the last one it has seen start, and its bound on the number of
+    rounds has to allow for them — it refused such walks while their last rounds were still in the queue (found by
+    scripts/walk_soak.py in round 4).  Same results as the single-kernel walk, bit for bit."""
+    w = make_workload(3)
+    with GpuRVModel(w.fixedpardict, w.table, w.parnames, priordict=w.priordict()) as m:
+        cube, theta, logl, lstar, chol = _start(m, w, 3000, seed=91, quantile=0.7)
+        wr = wrapped_params(m.parnames)
+        for max_rounds, nsteps in ((1, 20), (3, 11), (1, 1)):
+            monkeypatch.setenv("RVLL_WALK_ROUNDS", "0")
+            ref = m.slice_walk(cube, theta, logl, lstar, chol, wr, nsteps=nsteps, max_rounds=max_rounds, seed=5)
+            for depth in (None, "1", "9"):
+                monkeypatch.setenv("RVLL_WALK_ROUNDS", "1")
+                if depth:
+                    monkeypatch.setenv("RVLL_ROUNDS_DEPTH", depth)
+                got = m.slice_walk(cube, theta, logl, lstar, chol, wr, nsteps=nsteps, max_rounds=max_rounds, seed=5)
+                assert m.slice_walk_rounds() > 0
+                if depth:
+                    monkeypatch.delenv("RVLL_ROUNDS_DEPTH")
+                assert all(np.array_equal(a, b) for a, b in zip(got[:3], ref[:3])) and got[3] == ref[3], (max_rounds, nsteps, depth)
+            monkeypatch.delenv("RVLL_WALK_ROUNDS")
+
+
 def test_queue_serves_rows_with_nothing_left_to_do_and_a_ragged_last_workgroup(gpu_required, monkeypatch):
     """Sizes around the queue's edges: fewer walkers than one workgroup holds, a walker count that is not a multiple of
     the group size, one workgroup serving every row."""
