@@ -75,6 +75,22 @@ int sync_other_lanes(rvll_handle* h)
     return RVLL_OK;
 }
 
+// A request goes out as the legacy word (models of more than kServerSlotDims parameters: the kernel polls it, then fetches theta) AND
+// through the slots (rvll_kernels.h, ServerCtl::in): every value first, then the word beside every value — x86 keeps the order of
+// the stores, the release fence the compiler's.
+void server_post(rvll_handle* h, unsigned long long request, const double* row)
+{
+    rvll::ServerCtl* c = h->srv;
+    const int D = h->L.ndim;
+    if (row) memcpy(c->theta, row, sizeof(double) * (size_t)D);
+    if (D <= rvll::kServerSlotDims) {
+        if (row) for (int i = 0; i < D; ++i) c->in[i].v = row[i];
+        __atomic_thread_fence(__ATOMIC_RELEASE);
+        for (int i = 0; i < D; ++i) __atomic_store_n(&c->in[i].word, request, __ATOMIC_RELAXED);
+    }
+    __atomic_store_n(&c->request, request, __ATOMIC_RELEASE);
+}
+
 // Ask a running scalar-call server to leave and wait for it.  Every entry point other than the scalar call
 // itself goes through use_device(), so the persistent kernel never coexists with allocations, frees or
 // collectives of its own handle (hipFree and friends synchronise the whole device).
@@ -82,7 +98,7 @@ int server_stop(rvll_handle* h)
 {
     if (!h->srv_running || h->srv_dead) return RVLL_OK;
     const unsigned long long request = ((unsigned long long)rvll::kServerQuit << 32) | (unsigned)++h->srv_seq;
-    __atomic_store_n(&h->srv->request, request, __ATOMIC_RELEASE);
+    server_post(h, request, nullptr);
     hipError_t e = hipStreamSynchronize(h->srv_stream);
     h->srv_last = request;
     h->srv_running = false;
@@ -1026,10 +1042,9 @@ int scalar_call(rvll_handle* h, unsigned op, const double* theta, double* logL, 
         int rc = sync_other_lanes(h);
         if (rc) return rc;
     }
-    memcpy(c->theta, theta, sizeof(double) * (size_t)h->L.ndim);
     const unsigned number = (unsigned)++h->srv_seq;
     const unsigned long long request = ((unsigned long long)op << 32) | number;
-    __atomic_store_n(&c->request, request, __ATOMIC_RELEASE);
+    server_post(h, request, theta);
     if (!h->srv_running) { int rc = server_start(h); if (rc) return rc; }
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 0;; ++spins) {
@@ -1048,7 +1063,7 @@ int scalar_call(rvll_handle* h, unsigned op, const double* theta, double* logL, 
             // really stuck, a stream synchronisation would never return.  The kernel also leaves by itself after its
             // idle timeout; the handle refuses further scalar calls and the caller should exit, not retry.
             const unsigned long long quit = ((unsigned long long)rvll::kServerQuit << 32) | (unsigned)++h->srv_seq;
-            __atomic_store_n(&c->request, quit, __ATOMIC_RELEASE);
+            server_post(h, quit, nullptr);
             h->srv_last = quit;
             h->srv_dead = true;
             h->srv_enabled = false;

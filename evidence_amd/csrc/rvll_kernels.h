@@ -238,8 +238,16 @@ struct ServerCtl {
     alignas(64) unsigned int state;           // kServerRunning (host, before launch) / kServerExited (device, on exit)
     alignas(64) ServerAnswer answer;          // device -> host: number == the request's number when logL/flags
                                               // (and, for the prior op, theta) are complete
-    alignas(64) double theta[kServerMaxDim];
+    alignas(64) double theta[kServerMaxDim];  // up to kServerSlotDims parameters: device -> host only (the prior op's result)
+    // Round 4: the request AND its row in one read.  Up to kServerSlotDims parameters, the host writes value i and — after all the
+    // values — the request word into slot i; the kernel's first wave polls the slots with one 16-byte load a lane and takes the
+    // request when every slot carries the same new word: the values are then in its registers, and the PCIe round trip that used to
+    // fetch theta after the word had changed (1.2 us of a 10.8 us call) is gone.  (A 16-byte slot is read as it was at one instant,
+    // the same assumption the 16-byte answer rests on in the other direction; the values are older than the word they sit beside.)
+    struct Slot { double v; unsigned long long word; };
+    alignas(64) Slot in[64];
 };
+constexpr int kServerSlotDims = 64;           // one lane of the polling wave a parameter; larger models keep the two-step protocol
 // a = arguments of a one-point launch whose theta points into *ctl (device address of the block) and whose
 // logL / flags point at device-local scratch; the kernel answers requests that differ from `last` and leaves
 // after idle_ticks (100 MHz) without one

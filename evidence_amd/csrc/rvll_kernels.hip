@@ -155,16 +155,36 @@ void scalar_server_kernel(const LoglikeArgs a, ServerCtl* ctl, unsigned long lon
     LogdetPre pre;                                    // this thread's share of the epoch table for the per-point normalisation:
     logdet_preload(a, pre);                           // fetched once, it never changes between requests (rvll_tile.h)
     for (;;) {
-        if (threadIdx.x == 0) {
+        double* trow = reinterpret_cast<double*>(word + 2);
+        const bool slots = a.D <= kServerSlotDims;                       // (uniform) request and row arrive together: ServerCtl::in
+        if (threadIdx.x < kWave) {
+            const int lane = threadIdx.x;
             const unsigned long long t0 = wall_clock64();
-            unsigned long long r, stop = 0;
+            unsigned long long r = last, stop = 0;
+            typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
             for (unsigned polls = 1;; ++polls) {      // one PCIe read per poll; the clock only every 64 polls
-                r = __hip_atomic_load(&ctl->request, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-                if (r != last) { stop = (unsigned)(r >> 32) == kServerQuit; break; }
-                if ((polls & 63u) == 0u && wall_clock64() - t0 > idle_ticks) { stop = 1; break; }
+                if (slots) {
+                    u64x2 sl = {0ull, 0ull};
+                    if (lane < a.D) sl = *reinterpret_cast<const volatile u64x2*>(&ctl->in[lane]);     // volatile: system-scope cache bits
+                    r = __builtin_amdgcn_readfirstlane((unsigned)sl.y) | ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(sl.y >> 32)) << 32);
+                    const bool all_same = __builtin_amdgcn_ballot_w64(lane < a.D && sl.y != r) == 0;
+                    if (all_same && r != last) {
+                        if (lane < a.D) trow[lane] = __builtin_bit_cast(double, sl.x);
+                        stop = (unsigned)(r >> 32) == kServerQuit;
+                        break;
+                    }
+                    // (three such reads in flight a third of a round trip apart, to see a request sooner, were measured: 12.9 us a call
+                    // against 9.9 — the waits on the oldest read wait for the youngest too; profiles/r04_call_latency.txt)
+                } else {
+                    r = __hip_atomic_load(&ctl->request, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                    if (r != last) { stop = (unsigned)(r >> 32) == kServerQuit; break; }
+                }
+                if ((polls & 63u) == 0u && __builtin_amdgcn_readfirstlane((int)(wall_clock64() - t0 > idle_ticks))) { stop = 1; break; }   // (one lane's clock decides for the wave)
             }
-            word[0] = r;
-            word[1] = stop;
+            if (lane == 0) {
+                word[0] = r;
+                word[1] = stop;
+            }
         }
         __syncthreads();
         const unsigned long long r = word[0];
@@ -177,8 +197,7 @@ void scalar_server_kernel(const LoglikeArgs a, ServerCtl* ctl, unsigned long lon
             // kServerPriorLogLike: the sampler's next call is loglike(of exactly this theta) — evaluate it now, from
             // the LDS copy of theta rather than back over PCIe, and send both with one answer.
             double* row = smem;
-            double* trow = reinterpret_cast<double*>(word + 2);
-            for (int d = threadIdx.x; d < a.D; d += kThreads) row[d] = ctl->theta[d];
+            for (int d = threadIdx.x; d < a.D; d += kThreads) row[d] = slots ? trow[d] : ctl->theta[d];
             __syncthreads();
             for (int d = threadIdx.x; d < a.D; d += kThreads) {
                 const double v = prior_is_heavy(a.priors[d].kind) ? prior_heavy(a.priors[d], row[d])
@@ -190,16 +209,18 @@ void scalar_server_kernel(const LoglikeArgs a, ServerCtl* ctl, unsigned long lon
             __syncthreads();
             if (op == kServerPriorLogLike) {
                 loglike_tile<PREC, kFusedNone, false, kThreads, false, true, true>(a, smem, 0, 1, trow, pre);
-                if (threadIdx.x == 0) {
-                    ans.logL = __hip_atomic_load(a.logL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ans.flags = __hip_atomic_load(a.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (threadIdx.x == 0) {               // the point's sums are in LDS (this thread wrote them out itself: tile_write_point)
+                    int f;
+                    ans.logL = tile_point_result(a, tile_views(a, smem), 0, f);
+                    ans.flags = f;
                 }
             }
         } else if (op == kServerLogLike) {
-            loglike_tile<PREC, kFusedNone, false, kThreads, false, true, true>(a, smem, 0, 1, nullptr, pre);
-            if (threadIdx.x == 0) {                   // thread 0 wrote a.logL[0] / a.flags[0] itself
-                ans.logL = __hip_atomic_load(a.logL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                ans.flags = __hip_atomic_load(a.flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            loglike_tile<PREC, kFusedNone, false, kThreads, false, true, true>(a, smem, 0, 1, slots ? trow : nullptr, pre);
+            if (threadIdx.x == 0) {                   // straight from the tile's LDS accumulators (no trip through device memory)
+                int f;
+                ans.logL = tile_point_result(a, tile_views(a, smem), 0, f);
+                ans.flags = f;
             }
         }                                             // any other op: acknowledged only (round-trip probe)
         if (threadIdx.x == 0) {
