@@ -76,8 +76,8 @@ int sync_other_lanes(rvll_handle* h)
 }
 
 // A request goes out as the legacy word (models of more than kServerSlotDims parameters: the kernel polls it, then fetches theta) AND
-// through the slots (rvll_kernels.h, ServerCtl::in): every value first, then the word beside every value — x86 keeps the order of
-// the stores, the release fence the compiler's.
+// through the slots (rvll_kernels.h, ServerCtl::in): every value, then beside every value the word keyed with that value — a slot
+// read torn or early does not decode to the request, so nothing rests on store order or on how the link splits a read.
 void server_post(rvll_handle* h, unsigned long long request, const double* row)
 {
     rvll::ServerCtl* c = h->srv;
@@ -86,7 +86,11 @@ void server_post(rvll_handle* h, unsigned long long request, const double* row)
     if (D <= rvll::kServerSlotDims) {
         if (row) for (int i = 0; i < D; ++i) c->in[i].v = row[i];
         __atomic_thread_fence(__ATOMIC_RELEASE);
-        for (int i = 0; i < D; ++i) __atomic_store_n(&c->in[i].word, request, __ATOMIC_RELAXED);
+        for (int i = 0; i < D; ++i) {                                   // the word of a slot is keyed with the slot's value (ServerCtl)
+            unsigned long long vb;
+            memcpy(&vb, &c->in[i].v, sizeof vb);
+            __atomic_store_n(&c->in[i].word, request ^ rvll::ServerCtl::slot_key(vb), __ATOMIC_RELAXED);
+        }
     }
     __atomic_store_n(&c->request, request, __ATOMIC_RELEASE);
 }

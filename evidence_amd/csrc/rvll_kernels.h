@@ -242,10 +242,13 @@ struct ServerCtl {
     // Round 4: the request AND its row in one read.  Up to kServerSlotDims parameters, the host writes value i and — after all the
     // values — the request word into slot i; the kernel's first wave polls the slots with one 16-byte load a lane and takes the
     // request when every slot carries the same new word: the values are then in its registers, and the PCIe round trip that used to
-    // fetch theta after the word had changed (1.2 us of a 10.8 us call) is gone.  (A 16-byte slot is read as it was at one instant,
-    // the same assumption the 16-byte answer rests on in the other direction; the values are older than the word they sit beside.)
+    // fetch theta after the word had changed (1.2 us of a 10.8 us call) is gone.
+    // The word of a slot is the request XOR-ed with the slot's own value (rotated): a slot whose two halves were not read at one
+    // instant — or a word that arrived before its value — does not decode to the request the other slots carry, and the poll
+    // simply comes round again; nothing rests on how the link splits a read or orders the writes.
     struct Slot { double v; unsigned long long word; };
     alignas(64) Slot in[64];
+    static __host__ __device__ __forceinline__ unsigned long long slot_key(unsigned long long vbits) { return (vbits << 17) | (vbits >> 47); }
 };
 constexpr int kServerSlotDims = 64;           // one lane of the polling wave a parameter; larger models keep the two-step protocol
 // a = arguments of a one-point launch whose theta points into *ctl (device address of the block) and whose

@@ -166,8 +166,9 @@ void scalar_server_kernel(const LoglikeArgs a, ServerCtl* ctl, unsigned long lon
                 if (slots) {
                     u64x2 sl = {0ull, 0ull};
                     if (lane < a.D) sl = *reinterpret_cast<const volatile u64x2*>(&ctl->in[lane]);     // volatile: system-scope cache bits
-                    r = __builtin_amdgcn_readfirstlane((unsigned)sl.y) | ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(sl.y >> 32)) << 32);
-                    const bool all_same = __builtin_amdgcn_ballot_w64(lane < a.D && sl.y != r) == 0;
+                    const unsigned long long mine = sl.y ^ ServerCtl::slot_key(sl.x);      // the request this slot's (value, word) decode to
+                    r = __builtin_amdgcn_readfirstlane((unsigned)mine) | ((unsigned long long)__builtin_amdgcn_readfirstlane((unsigned)(mine >> 32)) << 32);
+                    const bool all_same = __builtin_amdgcn_ballot_w64(lane < a.D && mine != r) == 0;
                     if (all_same && r != last) {
                         if (lane < a.D) trow[lane] = __builtin_bit_cast(double, sl.x);
                         stop = (unsigned)(r >> 32) == kServerQuit;
