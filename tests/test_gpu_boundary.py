@@ -433,3 +433,39 @@ def test_every_transport_threshold_one_row_either_side(gpu_required):
             th, got, fl = m.prior_loglike_batch(cube[o:o + n], return_flags=True)
             assert np.array_equal(th, theta[o:o + n]) and np.array_equal(got, logl[o:o + n]) and \
                 np.array_equal(fl, flags[o:o + n]), ("prior_loglike", n)
+
+
+def test_scalar_server_with_more_parameters_than_its_polling_wave_has_lanes(gpu_required):
+    """Round 4: up to 64 parameters a scalar request and its row arrive in one read (the request word beside every value,
+    rvll_kernels.h ServerCtl::in); a larger model keeps the two-step protocol (word, then the row fetched by the tile).  A
+    14-planet model (74 free parameters): the server's answers are the batch path's bits either way, the same theta twice in a
+    row included (nothing in a slot changes but the request), and a 13-parameter model next to it exercises the one-read path."""
+    w = make_workload(3)
+    rng = np.random.default_rng(9)
+    two_pi = 2 * np.pi
+
+    def model_of(nplanets):
+        names = ["harps_jitter", "harps_offset", "hires_jitter", "hires_offset"]
+        for n in range(1, nplanets + 1):
+            names += [f"planet{n}_{k}" for k in ("ecc", "k1", "ma0", "omega", "period")]
+        names = sorted(names)
+        fixed = {f"planet{n}_epoch": 51000.0 for n in range(1, nplanets + 1)}
+        cols = []
+        for name in names:
+            kind = name.split("_")[1]
+            lo, hi = {"jitter": (0.0, 5.0), "offset": (-5.0, 5.0), "ecc": (0.0, 0.6), "k1": (0.1, 10.0), "ma0": (0.0, two_pi),
+                      "omega": (0.0, two_pi), "period": (2.0, 500.0)}[kind]
+            cols.append(rng.uniform(lo, hi, 40))
+        return fixed, names, np.column_stack(cols)
+
+    for nplanets in (14, 2):
+        fixed, names, theta = model_of(nplanets)
+        with GpuRVModel(fixed, w.table, names) as m:
+            assert m.ndim == 5 * nplanets + 4
+            want = m.log_likelihood_batch(theta)
+            assert np.isfinite(want).all()
+            m.scalar_server(True)
+            got = np.array([m.log_likelihood(x) for x in theta])
+            again = np.array([m.log_likelihood(theta[7]) for _ in range(5)])
+            m.scalar_server(False)
+            assert np.array_equal(got, want) and (again == want[7]).all(), nplanets
