@@ -24,6 +24,11 @@ namespace rvll {
 
 namespace {
 
+#ifdef RVLL_AB_NO_NP                   // (measurement builds only: without the instantiations for a compile-time planet count)
+constexpr bool kPlanetCountKernels = false;
+#else
+constexpr bool kPlanetCountKernels = true;
+#endif
 #ifdef RVLL_AB_NO_LEAN                 // (measurement builds only: scripts/build_variants.sh)
 constexpr bool kLeanKernels = false;
 #else
@@ -35,7 +40,8 @@ constexpr bool kLeanKernels = true;
 // EXTRAS = false: the instantiation for models without drift and without linear activity terms — most of them, the
 // headline configuration among them: the item loop then carries neither those branches nor the scalar registers they hold
 // across it (the kernel sits at its 106; profiles/r03_isa_budget_loglike_cu.txt)
-template <int PREC, bool TRACE, int FUSED = kFusedNone, bool EXTRAS = true>
+// NP > 0: the planet count at compile time (rvll_tile.h, eval_item): the lean fp64 kernels at one and three planets
+template <int PREC, bool TRACE, int FUSED = kFusedNone, bool EXTRAS = true, int NP = 0>
 __global__ __launch_bounds__(kCuThreads) __attribute__((flatten))
 void loglike_cu_kernel(const LoglikeArgs a)
 {
@@ -43,12 +49,12 @@ void loglike_cu_kernel(const LoglikeArgs a)
     const long long p0 = (long long)blockIdx.x * a.PB;
     const int npts = (int)min((long long)a.PB, a.B - p0);
     if (npts <= 0) return;
-    loglike_tile<PREC, FUSED, TRACE, kCuThreads, true, EXTRAS>(a, smem, p0, npts);
+    loglike_tile<PREC, FUSED, TRACE, kCuThreads, true, EXTRAS, false, NP>(a, smem, p0, npts);
 }
 
 // 4 workgroups of 256 per CU (4 waves/SIMD): caps the kernel at 128 VGPRs
 // FUSED: kFusedNone (theta rows in) or kFusedSlim (unit-cube rows in, verified-table quantiles; rvll_tile.h)
-template <int PREC, int FUSED, bool EXTRAS = true>
+template <int PREC, int FUSED, bool EXTRAS = true, int NP = 0>
 __global__ __launch_bounds__(kThreads, 4) __attribute__((flatten))      // flatten: the prior routines of the fused
 void loglike_kernel(const LoglikeArgs a)                                // form must live under the same VGPR cap
 {
@@ -56,7 +62,7 @@ void loglike_kernel(const LoglikeArgs a)                                // form 
     const long long p0 = (long long)blockIdx.x * a.PB;
     const int npts = (int)min((long long)a.PB, a.B - p0);
     if (npts <= 0) return;
-    loglike_tile<PREC, FUSED, false, kThreads, false, EXTRAS>(a, smem, p0, npts);
+    loglike_tile<PREC, FUSED, false, kThreads, false, EXTRAS, false, NP>(a, smem, p0, npts);
 }
 
 
@@ -77,7 +83,7 @@ void rounds_step_kernel(const RoundsArgs g, const int r)
     rounds_step(g, r, (int)blockIdx.x, smem);
 }
 
-template <int PREC, bool EXTRAS>
+template <int PREC, bool EXTRAS, int NP = 0>
 __global__ __launch_bounds__(kThreads, 4) __attribute__((flatten))
 void rounds_tiles_kernel(const LoglikeArgs a, const RoundsTiles o, const int r)
 {
@@ -90,7 +96,7 @@ void rounds_tiles_kernel(const LoglikeArgs a, const RoundsTiles o, const int r)
     const long long p0 = (long long)blockIdx.x * per;
     const int npts = (int)min((long long)per, (long long)B - p0);
     if (npts <= 0) return;
-    loglike_tile<PREC, kFusedNone, false, kThreads, false, EXTRAS>(a, smem, p0, npts);
+    loglike_tile<PREC, kFusedNone, false, kThreads, false, EXTRAS, false, NP>(a, smem, p0, npts);
     const TileLds L = tile_views(a, smem);
     for (int pl = threadIdx.x; pl < npts; pl += kThreads) {
         int f;
@@ -454,8 +460,13 @@ hipError_t launch_loglike(const LoglikeArgs& a, hipStream_t stream)
     case RVLL_PREC_MIXED: hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_MIXED, kFusedNone>), grid, block, lds, stream, a); break;
     case RVLL_PREC_FP32:  hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP32, kFusedNone>), grid, block, lds, stream, a); break;
     default:
-        if (kLeanKernels && !a.has_drift && a.nlin == 0) hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP64, kFusedNone, false>), grid, block, lds, stream, a);
-        else                             hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP64, kFusedNone>), grid, block, lds, stream, a);
+        if (kLeanKernels && !a.has_drift && a.nlin == 0) {
+            if (kPlanetCountKernels && a.Np == 3)      hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP64, kFusedNone, false, 3>), grid, block, lds, stream, a);
+            else if (kPlanetCountKernels && a.Np == 1) hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP64, kFusedNone, false, 1>), grid, block, lds, stream, a);
+            else                                       hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP64, kFusedNone, false>), grid, block, lds, stream, a);
+        } else {
+            hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP64, kFusedNone>), grid, block, lds, stream, a);
+        }
         break;
     }
     return hipGetLastError();
@@ -481,6 +492,8 @@ hipError_t launch_loglike_cu(const LoglikeArgs& a, int grid, hipStream_t stream)
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(loglike_cu_kernel<RVLL_PREC_FP32, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(loglike_cu_kernel<RVLL_PREC_FP64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(loglike_cu_kernel<RVLL_PREC_FP64, false, kFusedNone, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(loglike_cu_kernel<RVLL_PREC_FP64, false, kFusedNone, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(loglike_cu_kernel<RVLL_PREC_FP64, false, kFusedNone, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(loglike_cu_kernel<RVLL_PREC_FP64, false, kFusedSlim>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(loglike_cu_kernel<RVLL_PREC_MIXED, false, kFusedSlim>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(loglike_cu_kernel<RVLL_PREC_FP32, false, kFusedSlim>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
@@ -501,8 +514,13 @@ hipError_t launch_loglike_cu(const LoglikeArgs& a, int grid, hipStream_t stream)
     case RVLL_PREC_MIXED: hipLaunchKernelGGL((loglike_cu_kernel<RVLL_PREC_MIXED, false>), g, block, lds, stream, a); break;
     case RVLL_PREC_FP32:  hipLaunchKernelGGL((loglike_cu_kernel<RVLL_PREC_FP32, false>), g, block, lds, stream, a); break;
     default:
-        if (kLeanKernels && !a.has_drift && a.nlin == 0) hipLaunchKernelGGL((loglike_cu_kernel<RVLL_PREC_FP64, false, kFusedNone, false>), g, block, lds, stream, a);
-        else                             hipLaunchKernelGGL((loglike_cu_kernel<RVLL_PREC_FP64, false>), g, block, lds, stream, a);
+        if (kLeanKernels && !a.has_drift && a.nlin == 0) {
+            if (kPlanetCountKernels && a.Np == 3)      hipLaunchKernelGGL((loglike_cu_kernel<RVLL_PREC_FP64, false, kFusedNone, false, 3>), g, block, lds, stream, a);
+            else if (kPlanetCountKernels && a.Np == 1) hipLaunchKernelGGL((loglike_cu_kernel<RVLL_PREC_FP64, false, kFusedNone, false, 1>), g, block, lds, stream, a);
+            else                                       hipLaunchKernelGGL((loglike_cu_kernel<RVLL_PREC_FP64, false, kFusedNone, false>), g, block, lds, stream, a);
+        } else {
+            hipLaunchKernelGGL((loglike_cu_kernel<RVLL_PREC_FP64, false>), g, block, lds, stream, a);
+        }
         break;
     }
     return hipGetLastError();
@@ -567,8 +585,9 @@ hipError_t launch_rounds_tiles(const LoglikeArgs& a, const RoundsTiles& o, int t
     case RVLL_PREC_MIXED: hipLaunchKernelGGL((rounds_tiles_kernel<RVLL_PREC_MIXED, true>), grid, block, lds, stream, a, o, round); break;
     case RVLL_PREC_FP32:  hipLaunchKernelGGL((rounds_tiles_kernel<RVLL_PREC_FP32, true>), grid, block, lds, stream, a, o, round); break;
     default:
-        if (lean) hipLaunchKernelGGL((rounds_tiles_kernel<RVLL_PREC_FP64, false>), grid, block, lds, stream, a, o, round);
-        else      hipLaunchKernelGGL((rounds_tiles_kernel<RVLL_PREC_FP64, true>), grid, block, lds, stream, a, o, round);
+        if (lean && kPlanetCountKernels && a.Np == 3) hipLaunchKernelGGL((rounds_tiles_kernel<RVLL_PREC_FP64, false, 3>), grid, block, lds, stream, a, o, round);
+        else if (lean) hipLaunchKernelGGL((rounds_tiles_kernel<RVLL_PREC_FP64, false>), grid, block, lds, stream, a, o, round);
+        else           hipLaunchKernelGGL((rounds_tiles_kernel<RVLL_PREC_FP64, true>), grid, block, lds, stream, a, o, round);
         break;
     }
     return hipGetLastError();

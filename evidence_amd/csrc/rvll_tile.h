@@ -280,7 +280,11 @@ struct ItemCtx {
 // hangs on the last bit of sin / cos, and glibc's are correctly rounded nearly always: 90 of 20000 points at e = 0.95 .. 0.9925
 // were beyond 1e-10 of the reference arithmetic with the ~1.2-ulp kernels, 2 with this (profiles/r04_high_ecc_parity.txt).  It lives in the
 // redo pass because inside the first pass its mere presence cost every launch 3.7 % (63.3 -> 65.6 us: scalar registers).
-template <int PREC, bool FAILCHECK, bool EXTRAS = true, bool CR = false>
+// NP: the planet count as a compile-time constant (0: a.Np at run time).  With it the planet loop unrolls and the per-planet LDS
+// addresses fold; instantiated for the lean fp64 batch kernels at one and three planets (rvll_kernels.hip): 63.5 -> 62.6 us at
+// cfg3 on the final tree of round 4 (it measured SLOWER on the tree before the redo pass got its cold-path hints:
+// profiles/r04_isa_budget_addendum.txt).  Same operations in the same order: same bits.
+template <int PREC, bool FAILCHECK, bool EXTRAS = true, bool CR = false, int NP = 0>
 __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx& cx, int pl, int j)
 {
     const double t  = a.t[j];
@@ -292,19 +296,13 @@ __device__ __forceinline__ double eval_item(const LoglikeArgs& a, const ItemCtx&
     double rvm = 0. + oj.x;                                   // rvmodel:187
     const double var = s2 + oj.y;                             // rvmodel:189-192 (oj.y = jitter^2 or 0)
 
-#ifdef RVLL_NP_CONST                  // (measurement builds only: the planet count as a compile-time constant)
-    constexpr int Np = RVLL_NP_CONST;
-#else
-    const int Np = a.Np;
-#endif
+    const int Np = NP > 0 ? NP : a.Np;
     if (Np > 0) {
         const bool wide = __builtin_amdgcn_readfirstlane(*cx.wide) != 0;
         bool point_failed = false;
         if constexpr (FAILCHECK) point_failed = cx.anyfail[pl] != 0;
         double ksum = 0.;
-#ifdef RVLL_NP_CONST
-#pragma unroll
-#endif
+#pragma clang loop unroll_count(NP > 0 ? NP : 1)
         for (int ip = 0; ip < Np; ++ip) {
             const double* P = cx.pp + (pl * Np + ip) * kPlanetFields;
             const double2 p01 = *reinterpret_cast<const double2*>(P);       // w, epoch
@@ -960,7 +958,7 @@ __device__ __forceinline__ void tile_write_point(const LoglikeArgs& __restrict__
 // buffer nothing else reads; no stamp executes in the product kernels.
 // PRE: the caller holds its lanes' share of the epoch table for the per-point normalisation in registers (LogdetPre; the
 // scalar-call server) — used when the tile has one point and the preload is valid, ignored otherwise
-template <int PREC, int FUSED, bool TRACE = false, int NT = kThreads, bool DYN = false, bool EXTRAS = true, bool PRE = false>
+template <int PREC, int FUSED, bool TRACE = false, int NT = kThreads, bool DYN = false, bool EXTRAS = true, bool PRE = false, int NP = 0>
 __device__ __forceinline__ __attribute__((flatten)) void loglike_tile(const LoglikeArgs& __restrict__ a, double* __restrict__ smem, long long p0, int npts,
                                                                       const double* cube_rows = nullptr, const LogdetPre& pre = LogdetPre{}
 #ifdef RVLL_WALK_TRACE                 // diagnostic build of the walk only: thread 0 sums the tile's own phases into tph[0..3]
@@ -1089,7 +1087,7 @@ __device__ __forceinline__ __attribute__((flatten)) void loglike_tile(const Logl
                 if (i < cend) {
                     int pl, j;
                     item_of(r * kWave, lane, a.Ne, pl, j);
-                    contrib[i] = eval_item<PREC, false, EXTRAS>(a, cx, pl, j);
+                    contrib[i] = eval_item<PREC, false, EXTRAS, false, NP>(a, cx, pl, j);
                 }
             }
             if constexpr (TRACE) { if (tid == 0) tr[4] = __builtin_amdgcn_s_memrealtime(); }
@@ -1116,7 +1114,7 @@ __device__ __forceinline__ __attribute__((flatten)) void loglike_tile(const Logl
             for (int i = base + tid; i < cend; i += NT) {
                 int pl, j;
                 item_of(i - lane, lane, a.Ne, pl, j);            // i - lane = base + 64 wave + k NT: the same for the whole wave
-                contrib[i - base] = eval_item<PREC, false, EXTRAS>(a, cx, pl, j);
+                contrib[i - base] = eval_item<PREC, false, EXTRAS, false, NP>(a, cx, pl, j);
             }
             if constexpr (TRACE) { if (lane == 0) tr[2 + wave] = __builtin_amdgcn_s_memrealtime(); }
         }
@@ -1131,7 +1129,7 @@ __device__ __forceinline__ __attribute__((flatten)) void loglike_tile(const Logl
             for (int i = base + tid; i < cend; i += NT) {
                 const int pl = i / a.Ne;
                 if (L.anyfail[pl] || contrib[i - base] != contrib[i - base])       // a point with an itmax failure; an item left as NaN
-                    contrib[i - base] = eval_item<PREC, true, EXTRAS, PREC == RVLL_PREC_FP64>(a, cx, pl, i - pl * a.Ne);
+                    contrib[i - base] = eval_item<PREC, true, EXTRAS, PREC == RVLL_PREC_FP64, NP>(a, cx, pl, i - pl * a.Ne);
             }
             __syncthreads();
         }
