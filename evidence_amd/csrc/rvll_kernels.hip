@@ -457,13 +457,21 @@ hipError_t launch_loglike(const LoglikeArgs& a, hipStream_t stream)
     const size_t lds = loglike_lds_bytes(a);
     const dim3 grid((unsigned)blocks), block(kThreads);
     switch (a.precision) {
-    case RVLL_PREC_MIXED: hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_MIXED, kFusedNone>), grid, block, lds, stream, a); break;
-    case RVLL_PREC_FP32:  hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP32, kFusedNone>), grid, block, lds, stream, a); break;
+    case RVLL_PREC_MIXED:
+        if (kPlanetCountKernels && a.Np == 5) hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_MIXED, kFusedNone, true, 5>), grid, block, lds, stream, a);
+        else                                  hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_MIXED, kFusedNone>), grid, block, lds, stream, a);
+        break;
+    case RVLL_PREC_FP32:
+        if (kPlanetCountKernels && a.Np == 5) hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP32, kFusedNone, true, 5>), grid, block, lds, stream, a);
+        else                                  hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP32, kFusedNone>), grid, block, lds, stream, a);
+        break;
     default:
         if (kLeanKernels && !a.has_drift && a.nlin == 0) {
             if (kPlanetCountKernels && a.Np == 3)      hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP64, kFusedNone, false, 3>), grid, block, lds, stream, a);
             else if (kPlanetCountKernels && a.Np == 1) hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP64, kFusedNone, false, 1>), grid, block, lds, stream, a);
             else                                       hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP64, kFusedNone, false>), grid, block, lds, stream, a);
+        } else if (kPlanetCountKernels && a.Np == 5) {                   // (BASELINE configs[4]: five planets + drift)
+            hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP64, kFusedNone, true, 5>), grid, block, lds, stream, a);
         } else {
             hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP64, kFusedNone>), grid, block, lds, stream, a);
         }

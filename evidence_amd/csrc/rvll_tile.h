@@ -540,7 +540,7 @@ __device__ __forceinline__ bool pair_solve_f64(const LoglikeArgs& a, const ItemC
     return true;
 }
 
-template <int PREC, bool EXTRAS>
+template <int PREC, bool EXTRAS, int NP = 0>
 __device__ __forceinline__ void eval_item_pair(const LoglikeArgs& a, const ItemCtx& cx, int plA, int jA, int plB, int jB,
                                                double& outA, double& outB)
 {
@@ -549,9 +549,10 @@ __device__ __forceinline__ void eval_item_pair(const LoglikeArgs& a, const ItemC
     const double2 ojB = *reinterpret_cast<const double2*>(cx.ins + (plB * a.Ni + a.inst[jB]) * 2);
     double rvmA = 0. + ojA.x, rvmB = 0. + ojB.x;                            // rvmodel:187
     const double varA = a.s2[jA] + ojA.y, varB = a.s2[jB] + ojB.y;         // rvmodel:189-192
-    const int Np = a.Np;
+    const int Np = NP > 0 ? NP : a.Np;
     const f32x2 tolf = splat2((float)a.tol);
     double ksumA = 0., ksumB = 0.;
+#pragma clang loop unroll_count(NP > 0 ? NP : 1)
     for (int ip = 0; ip < Np; ++ip) {
         const double* PA = cx.pp + (plA * Np + ip) * kPlanetFields;
         const double* PB = cx.pp + (plB * Np + ip) * kPlanetFields;
@@ -1078,7 +1079,7 @@ __device__ __forceinline__ __attribute__((flatten)) void loglike_tile(const Logl
                         if (!okA) { plA = 0; jA = 0; }
                         if (!okB) { plB = plA; jB = jA; }
                         double oA, oB;
-                        eval_item_pair<PREC, EXTRAS>(a, cx, plA, jA, plB, jB, oA, oB);
+                        eval_item_pair<PREC, EXTRAS, NP>(a, cx, plA, jA, plB, jB, oA, oB);
                         if (okA) contrib[i] = oA;
                         if (okB) contrib[i2] = oB;
                         continue;
@@ -1103,7 +1104,7 @@ __device__ __forceinline__ __attribute__((flatten)) void loglike_tile(const Logl
                         item_of(wave2 ? i2 - lane : i - lane, lane, a.Ne, plB, jB);
                         if (!okB) { plB = plA; jB = jA; }
                         double oA, oB;
-                        eval_item_pair<PREC, EXTRAS>(a, cx, plA, jA, plB, jB, oA, oB);
+                        eval_item_pair<PREC, EXTRAS, NP>(a, cx, plA, jA, plB, jB, oA, oB);
                         contrib[i - base] = oA;
                         if (okB) contrib[i2 - base] = oB;
                     }
