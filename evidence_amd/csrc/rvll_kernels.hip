@@ -503,6 +503,7 @@ hipError_t launch_loglike_cu(const LoglikeArgs& a, int grid, hipStream_t stream)
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(loglike_cu_kernel<RVLL_PREC_FP64, false, kFusedNone, false, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(loglike_cu_kernel<RVLL_PREC_FP64, false, kFusedNone, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(loglike_cu_kernel<RVLL_PREC_FP64, false, kFusedSlim>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(loglike_cu_kernel<RVLL_PREC_FP64, false, kFusedSlim, true, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(loglike_cu_kernel<RVLL_PREC_MIXED, false, kFusedSlim>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(loglike_cu_kernel<RVLL_PREC_FP32, false, kFusedSlim>), hipFuncAttributeMaxDynamicSharedMemorySize, lim);
         if (e != hipSuccess) return e;
@@ -514,7 +515,10 @@ hipError_t launch_loglike_cu(const LoglikeArgs& a, int grid, hipStream_t stream)
         switch (a.precision) {
         case RVLL_PREC_MIXED: hipLaunchKernelGGL((loglike_cu_kernel<RVLL_PREC_MIXED, false, kFusedSlim>), g, block, lds, stream, a); break;
         case RVLL_PREC_FP32:  hipLaunchKernelGGL((loglike_cu_kernel<RVLL_PREC_FP32, false, kFusedSlim>), g, block, lds, stream, a); break;
-        default:              hipLaunchKernelGGL((loglike_cu_kernel<RVLL_PREC_FP64, false, kFusedSlim>), g, block, lds, stream, a); break;
+        default:
+            if (kPlanetCountKernels && a.Np == 3) hipLaunchKernelGGL((loglike_cu_kernel<RVLL_PREC_FP64, false, kFusedSlim, true, 3>), g, block, lds, stream, a);
+            else                                  hipLaunchKernelGGL((loglike_cu_kernel<RVLL_PREC_FP64, false, kFusedSlim>), g, block, lds, stream, a);
+            break;
         }
         return hipGetLastError();
     }
@@ -666,7 +670,10 @@ hipError_t launch_prior_loglike(const LoglikeArgs& a, hipStream_t stream)
     switch (a.precision) {
     case RVLL_PREC_MIXED: hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_MIXED, kFusedSlim>), grid, block, lds, stream, a); break;
     case RVLL_PREC_FP32:  hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP32, kFusedSlim>), grid, block, lds, stream, a); break;
-    default:              hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP64, kFusedSlim>), grid, block, lds, stream, a); break;
+    default:
+        if (kPlanetCountKernels && a.Np == 3) hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP64, kFusedSlim, true, 3>), grid, block, lds, stream, a);
+        else                                  hipLaunchKernelGGL((loglike_kernel<RVLL_PREC_FP64, kFusedSlim>), grid, block, lds, stream, a);
+        break;
     }
     return hipGetLastError();
 }

@@ -49,7 +49,7 @@ namespace {
 // number of completed moves in steps_done; the host finishes those walkers with the FAT instantiation (full solvers
 // inline, 2 waves per SIMD), whose counter-based random numbers make it retrace the interrupted move exactly — so
 // the pair returns what a FAT-only walk would.
-template <int PREC, bool FAT>
+template <int PREC, bool FAT, int NP = 0>           // NP: the planet count at compile time (rvll_tile.h, eval_item), 0 = a.Np
 __global__ __launch_bounds__(kThreads, FAT ? 2 : RVLL_WALK_WAVES) __attribute__((flatten))
 void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
 {
@@ -293,9 +293,9 @@ void slice_walk_kernel(const LoglikeArgs a, const WalkArgs w)
         WALK_STAMP(1);
         // prior transform + log-L of the candidates: rows read from LDS, results left in LDS (and in the scratch rows)
 #ifdef RVLL_WALK_TRACE
-        loglike_tile<PREC, FAT ? kFusedFull : kFusedSlim>(a, smem, w0, nslots, cand, LogdetPre{}, tph);
+        loglike_tile<PREC, FAT ? kFusedFull : kFusedSlim, false, kThreads, false, true, false, NP>(a, smem, w0, nslots, cand, LogdetPre{}, tph);
 #else
-        loglike_tile<PREC, FAT ? kFusedFull : kFusedSlim>(a, smem, w0, nslots, cand);
+        loglike_tile<PREC, FAT ? kFusedFull : kFusedSlim, false, kThreads, false, true, false, NP>(a, smem, w0, nslots, cand);
 #endif
         // the walk's own phases are short and serial (a lane per walker, one thread for the bookkeeping): at the
         // default priority they get every fourth issue slot next to three workgroups in their item loops and a
@@ -796,7 +796,12 @@ hipError_t launch_slice_walk(const LoglikeArgs& a, const WalkArgs& w, bool fat, 
     switch (a.precision) {
     case RVLL_PREC_MIXED: RVLL_WALK(RVLL_PREC_MIXED); break;
     case RVLL_PREC_FP32:  RVLL_WALK(RVLL_PREC_FP32); break;
-    default:              RVLL_WALK(RVLL_PREC_FP64); break;
+    default:
+#ifndef RVLL_AB_NO_NP                  // (measurement builds only: without the three-planet instantiation)
+        if (!fat && a.Np == 3) { RVLL_WALK_ONE((slice_walk_kernel<RVLL_PREC_FP64, false, 3>)); break; }
+#endif
+        RVLL_WALK(RVLL_PREC_FP64);
+        break;
     }
 #undef RVLL_WALK
 #undef RVLL_WALK_ONE
