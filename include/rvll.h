@@ -312,7 +312,9 @@ int rvll_live_dead(rvll_handle* h, int64_t* n_dead, double* theta, double* logl)
  * of the handle stops it first.  enable = 0 turns it off (default; RVLL_SCALAR_SERVER=1 in the environment turns
  * it on at rvll_create).  While it runs, calls that synchronise the whole device (hipMalloc / hipFree, also of
  * other handles in the process) wait until it is idle, i.e. at most the 5 ms, provided no other thread keeps
- * feeding it meanwhile.                                                                                      */
+ * feeding it meanwhile.  Round 4: up to 64 parameters the request word travels beside every value of the row (keyed with the
+ * value, so a torn read cannot pass for a request), the kernel sees request and row in ONE read and answers from its LDS sums:
+ * 9.7 - 10.3 us a call on an MI355X (10.8 before), 15.5 us for PolyChord's prior + loglike pair as one request.            */
 int rvll_scalar_server(rvll_handle* h, int32_t enable);
 
 /* ---- device-resident forms (no PCIe inside; used by bench and multi-GPU) -- */
